@@ -1,0 +1,174 @@
+/*
+ * rt355.h -- C ABI of the MI355X (gfx950) renderer for the per-pixel path of
+ * liz425/RayTracer.
+ *
+ * The reference has no FFI of its own: its render path is one C++ call,
+ *     void setPixels(Scene sce, Shader shd, int alias)      image_synthesis/main.cpp:339-376
+ * which fills the global `unsigned char *pixmap` (main.cpp:34).  This header is
+ * the boundary a maintainer of the reference binds in its place: plain C, plain
+ * pointers and sizes, no C++ or torch types.
+ *
+ * All geometry is `double`, exactly the values the reference objects hold after
+ * their constructors ran.  Colours are 3 x unsigned char (color.h:16-25).
+ *
+ * Threading: one render at a time per scene handle.  Errors: every entry point
+ * returns 0 on success or a negative RT355_ERR_* code; rt355_last_error() gives a
+ * thread-local message.  Nothing throws across this boundary.
+ */
+#ifndef RT355_H
+#define RT355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ---------------------------------------------------------------- */
+#define RT355_OK               0
+#define RT355_ERR_ARG         -1 /* null pointer, bad size, inconsistent indices          */
+#define RT355_ERR_UNSUPPORTED -2 /* feature of the reference outside the accelerated path */
+#define RT355_ERR_DEVICE      -3 /* HIP runtime error (message holds hipGetErrorString)   */
+#define RT355_ERR_NOMEM       -4
+
+/* ---- scene objects, in scene-list order ------------------------------------------ */
+/* Object kinds.  Values follow AnyObject::GetObjectType() strings
+ * ("Plane" anyobject.h:89, "Sphere" :161, "Mesh" :672). */
+#define RT355_OBJ_PLANE  0
+#define RT355_OBJ_SPHERE 1
+#define RT355_OBJ_MESH   2
+
+/* One entry of Scene::objs (main.cpp:229).  Order is significant: the closest-hit loop
+ * keeps the first object on equal t (main.cpp:68). */
+typedef struct rt355_object {
+    double p[3];      /* Plane::pi (anyobject.h:43) | Sphere::pCenter (:101)                 */
+    double n[3];      /* Plane::ni (:46), used as given (not normalised, :86)               */
+    double n0[3];     /* Plane::n0 (:44) | Sphere::n0 (:103); texture axes                  */
+    double n1[3];     /* Sphere::n1 (:104).  For a plane the library derives
+                         n1 = n0 x ni as the Plane ctor does (:57); this field is ignored. */
+    double n2[3];     /* Sphere::n2 (:105)                                                   */
+    double radius;    /* Sphere::radius (:102)                                               */
+    double ks;        /* AnyObject::ks (:22); must be 0 (no reflection recursion yet)        */
+    double fresnel;   /* AnyObject::fresnel (:21); must be 1 (no refraction yet)             */
+    double ior;       /* AnyObject::IOR (:20); carried, unused while fresnel == 1            */
+    int32_t type;     /* RT355_OBJ_*                                                         */
+    int32_t texture_type; /* AnyObject::texture_type (:29): 0 flat colour, 1 texture mapping */
+    int32_t tex0;     /* index of textures[0] (lit colour map)  or -1                        */
+    int32_t tex1;     /* index of textures[1] (dark colour map) or -1                        */
+    int32_t tri_begin;/* Mesh: first triangle in rt355_scene_desc::triangles                 */
+    int32_t tri_count;/* Mesh: number of triangles (Mesh::triangles, :541)                   */
+    uint8_t rgb[3];   /* the object's own `clr` (Plane :42, Sphere :100, Mesh :536)          */
+    uint8_t pad_[5];
+} rt355_object;
+
+/* One Triangle of a Mesh (anyobject.h:444-532).  The library derives `normal` and
+ * `p_center` exactly as the Triangle ctor does (:456-461). */
+typedef struct rt355_triangle {
+    double p0[3], p1[3], p2[3];
+    double uv0[2], uv1[2], uv2[2]; /* Triangle::UV_p0..2 (:451) */
+} rt355_triangle;
+
+/* One Texture (texture.h:23-79) after loading: `rgb` is width*height*3 bytes in the
+ * order the reference keeps them in memory (BMP row order, bottom row first, R,G,B
+ * after the swap at texture.h:73-78).  The bytes are copied by rt355_scene_create. */
+typedef struct rt355_texture {
+    const uint8_t *rgb;
+    double sx, sy;      /* Texture::sx, sy (texture.h:28-29) */
+    int32_t width, height;
+} rt355_texture;
+
+typedef struct rt355_scene_desc {
+    const rt355_object   *objects;   int32_t n_objects;   int32_t pad0_;
+    const rt355_triangle *triangles; int32_t n_triangles; int32_t pad1_;
+    const rt355_texture  *textures;  int32_t n_textures;  int32_t pad2_;
+} rt355_scene_desc;
+
+/* ---- camera, lights, shader -------------------------------------------------------- */
+/* The public camera fields of Scene (main.cpp:217-222).  The library derives
+ * n_view, p_center, n0, n1, p00 as Scene::SetCamera does (main.cpp:255-262). */
+typedef struct rt355_camera {
+    double v_up[3], v_view[3], p_eye[3];
+    double dist, s_x, s_y;
+} rt355_camera;
+
+/* light_src (light.h:12-56).  `direction` is the stored, already normalised member
+ * (light.h:30); the library does not normalise it again.  Types 0 directional, 1 point,
+ * 2 spot (soft spot, shader.h:332,370,426), 3 area (treated as a point light by
+ * Shader::shading, shader.h:80-82). */
+typedef struct rt355_light {
+    double position[3];
+    double direction[3];
+    double color[3];
+    int32_t type;
+    int32_t pad_;
+} rt355_light;
+
+/* Shader (shader.h:25-37): the private light list plus the three public colours. */
+typedef struct rt355_shader {
+    const rt355_light *lights;
+    int32_t n_lights;
+    uint8_t ambient[3];   /* Shader::ambient_color  */
+    uint8_t specular[3];  /* Shader::specular_color */
+    uint8_t border[3];    /* Shader::border_color   */
+    uint8_t pad_[3];
+} rt355_shader;
+
+/* ---- render options ------------------------------------------------------------------ */
+#define RT355_MODE_FAST  0 /* fp32 conservative candidate search + fp64 exact evaluation   */
+#define RT355_MODE_BRUTE 1 /* fp64 exact evaluation of every ray/primitive pair (debug)   */
+
+typedef struct rt355_opts {
+    int32_t width, height; /* the reference's globals (main.cpp:33)                         */
+    int32_t alias;         /* setPixels' third argument; only 0 is accelerated so far       */
+    int32_t row_begin;     /* slab [row_begin,row_end) of rows to render; 0,0 = whole frame */
+    int32_t row_end;
+    int32_t mode;          /* RT355_MODE_*                                                  */
+} rt355_opts;
+
+typedef struct rt355_stats {
+    uint64_t primary_rays;   /* camera rays cast                                            */
+    uint64_t shadow_rays;    /* shadow rays cast: (hit, light) pairs with N.L > 0           */
+    uint64_t pair_tests;     /* ray/primitive pairs examined by the candidate search        */
+    uint64_t exact_tests;    /* pairs evaluated by the fp64 reference formulas              */
+    uint64_t overflow_rays;  /* rays whose candidate list overflowed (re-done brute force)  */
+    double   ms_device;      /* HIP-event time of the device work of this call              */
+} rt355_stats;
+
+typedef struct rt355_scene rt355_scene; /* opaque, library-owned, bound to one HIP device */
+
+/* Flatten and upload a scene to the current HIP device.
+ * Replaces: the object-list walk done implicitly by every CalcIntersect call through
+ * vector<AnyObject*> (main.cpp:65-79); the reference has no upload step. */
+int rt355_scene_create(const rt355_scene_desc *desc, rt355_scene **out);
+void rt355_scene_destroy(rt355_scene *scene);
+
+/* Render rows [row_begin,row_end) into a caller-owned HOST pixmap of width*height*3
+ * bytes, RGB, row 0 = bottom scanline, index (y*width+x)*3.
+ * Replaces: setPixels(Scene, Shader, int alias) writing the global pixmap
+ * (main.cpp:339-376, called at main.cpp:640). */
+int rt355_render(rt355_scene *scene, const rt355_camera *cam, const rt355_shader *shader,
+                 const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats);
+
+/* Same, but the framebuffer is a DEVICE pointer (width*height*3 bytes) and the work is
+ * enqueued on `hip_stream` (a hipStream_t, NULL = default stream).  Returns after
+ * enqueueing; call rt355_scene_sync before reading `stats` or the pixels.
+ * No counterpart in the reference (it has no device memory); this is the entry point
+ * a GPU-resident pipeline and the benchmark use. */
+int rt355_render_device(rt355_scene *scene, const rt355_camera *cam,
+                        const rt355_shader *shader, const rt355_opts *opts,
+                        void *d_pixmap, void *hip_stream, rt355_stats *stats);
+
+/* Wait for the scene's outstanding render and fill the stats passed to it. */
+int rt355_scene_sync(rt355_scene *scene);
+
+/* Average HIP-event duration (ms) of the candidate-search kernel launches of the last
+ * synced render, and their count.  Used by the benchmark's roofline figure. */
+int rt355_scene_search_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *launches);
+
+const char *rt355_last_error(void);
+int rt355_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */

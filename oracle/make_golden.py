@@ -1,0 +1,106 @@
+"""Generate tests/golden/* from the reference's own code (oracle/_ref/libref_harness.so).
+
+Run in the container that has /root/reference:  python -m oracle.make_golden
+The outputs are data only: inputs (seeded, re-creatable from raytracer_amd.scenes) and the
+values the reference computed for them.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from raytracer_amd import binding as B
+from raytracer_amd import scenes as S
+from oracle.oracle_py import Reference
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def random_rays(n, seed, origin_box=((-40, -40, -20), (40, 40, 40))):
+    rng = S.SplitMix64(seed)
+    u = rng.array(n * 6).reshape(n, 6)
+    lo, hi = np.array(origin_box[0]), np.array(origin_box[1])
+    pe = lo + (hi - lo) * u[:, :3]
+    d = u[:, 3:] * 2 - 1
+    return np.concatenate([pe, d], axis=1)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    R = Reference()
+    meta = {}
+    # 1. golden frames
+    for name in S.SMALL_CASES:
+        sc, sh, cam, w, h = S.small_case(name)
+        frame = R.render(sc.pack(), cam, sh, B.opts(w, h))
+        np.save(os.path.join(OUT, f"frame_{name}.npy"), frame)
+        meta[name] = {"width": w, "height": h, "fnv1a64": f"{B.fnv1a64(frame):016x}"}
+    # 2. CalcIntersect known answers: rays aimed roughly at each object kind
+    sc, _, _, _, _ = S.small_case("mesh")
+    p = sc.pack()
+    rays = random_rays(400, 901, ((-20, -30, -5), (20, 5, 30)))
+    # aim half of them at the scene centre so that a good share hits
+    tgt = np.array([0.0, 4.0, -2.0])
+    rays[::2, 3:] = tgt - rays[::2, :3] + (rays[::2, 3:] * 6)
+    isect = {"rays": rays}
+    for obj in range(len(p.objects)):
+        isect[f"obj{obj}"] = R.intersect_many(p, obj, rays)
+    sc2, _, _, _, _ = S.small_case("inside")
+    p2 = sc2.pack()
+    rays2 = random_rays(300, 902, ((-10, -30, -8), (10, 0, 8)))
+    isect["rays_inside"] = rays2
+    for obj in range(len(p2.objects)):
+        isect[f"inside_obj{obj}"] = R.intersect_many(p2, obj, rays2)
+    np.savez_compressed(os.path.join(OUT, "intersect.npz"), **isect)
+    # 3. Color operator table (color.h:33-51)
+    rng = S.SplitMix64(903)
+    vals = [0.0, 0.5, 1.0, 0.999999, 1.003, 1.5, 2.0, -0.002, -1.0, -3.5 / 200, 1e10, -1e10, float("nan"),
+            float("inf"), 255.999 / 255, 256.0 / 255]
+    vals += list(rng.array(40) * 1.2 - 0.1)
+    cols = [(200, 100, 50), (255, 255, 255), (0, 1, 2), (221, 221, 221), (128, 127, 129)]
+    rows = []
+    for c in cols:
+        for v in vals:
+            rows.append([0, *c, 0, 0, 0, v, 0, 0, *R.color_op(0, c, v=v)])
+            if v != 0:
+                rows.append([1, *c, 0, 0, 0, v, 0, 0, *R.color_op(1, c, v=v)])
+            rows.append([3, *c, 0, 0, 0, v, 1 - v, v * 0.5, *R.color_op(3, c, v=v, v2=1 - v, v3=v * 0.5)])
+        for c2 in cols:
+            rows.append([2, *c, *c2, 0, 0, 0, *R.color_op(2, c, c2)])
+    np.save(os.path.join(OUT, "color_ops.npy"), np.array(rows, dtype=np.float64))
+    # 4. Texture lookups (texture.h:81-122) on a tiny 8x4 texture and a 32x16 one
+    tex = {}
+    for tag, (tw, th, sx, sy, seed) in {"t8x4": (8, 4, 1.0, 1.0, 904), "t32x16": (32, 16, 0.5, 0.25, 905)}.items():
+        t = B.Texture(S._small_texture(tw, th, seed), sx, sy)
+        uv = S.SplitMix64(seed + 50).array(600).reshape(300, 2)
+        uv[:4] = [[0, 0], [0.999999, 0.999999], [0.5, 0.5], [1.0, 1.0]]
+        ang = uv * np.array([2 * 3.1415927, 3.1415927])
+        tex[f"{tag}_rgb"] = t.rgb
+        tex[f"{tag}_s"] = np.array([sx, sy])
+        tex[f"{tag}_uv"] = uv
+        tex[f"{tag}_plane"] = R.texture_many(t, 0, uv)
+        tex[f"{tag}_ang"] = ang
+        tex[f"{tag}_sphere"] = R.texture_many(t, 1, ang)
+    np.savez_compressed(os.path.join(OUT, "texture_lookups.npz"), **tex)
+    # 5. values the survey recorded from a run of the reference main.cpp path
+    meta["baseline_md_samples"] = {
+        "800x600_1light": {"(0,0)": [181] * 3, "(400,300)": [11] * 3, "(200,300)": [65, 130, 65],
+                           "(600,200)": [180] * 3, "(400,75)": [181] * 3, "(799,599)": [170] * 3},
+        "800x600_2lights": {"(0,0)": [193] * 3, "(400,300)": [84] * 3, "(200,300)": [57, 116, 57],
+                            "(600,200)": [199] * 3, "(400,75)": [196] * 3, "(799,599)": [164] * 3},
+        "3840x2160_1light": {"(0,0)": [181] * 3, "(1920,1080)": [11] * 3, "(960,1080)": [157] * 3,
+                             "(2880,720)": [180] * 3, "(1920,270)": [181] * 3, "(3839,2159)": [161] * 3},
+    }
+    # larger frames: hashes only
+    for (w, h, nl) in [(800, 600, 1), (800, 600, 2)]:
+        frame = R.render(S.default_scene().pack(), S.default_camera(w, h), S.default_shader(nl), B.opts(w, h))
+        meta[f"default_{w}x{h}_{nl}light"] = {"fnv1a64": f"{B.fnv1a64(frame):016x}"}
+    with open(os.path.join(OUT, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,277 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Built only where
+// /root/reference is present (this container); output goes to oracle/_ref/ only.
+//
+// Compiles the reference's OWN headers (vector3D.h, color.h, texture.h, light.h,
+// view.h, anyobject.h, shader.h) where they lie, and drives their real
+// CalcIntersect / Shader::shading / Texture::GetColor* code from rt355 scene
+// descriptors, so that the C restatement (rt_oracle.c) and the HIP library can be
+// checked against what the reference itself computes.
+//
+// image_synthesis/main.cpp is NOT compiled: it needs <GLUT/GLUT.h>, which this image
+// does not have, and no stand-in is written for it.  The ~25 lines of main.cpp that sit
+// on the path (Scene::SetCamera 255-262, CalcView 269-276, the closest-hit loop of
+// CalcSubPixel 42-91, the alias==0 branch of CalcPixel 326-332 and setPixels 355-370)
+// are therefore re-expressed below with the reference's own vector/colour types.  That
+// part is pinned by the frame hashes BASELINE.md records from a run of main.cpp itself.
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+// same order as main.cpp:17-21
+#include "vector3D.h"
+#include "color.h"
+#include "texture.h"
+#include "shader.h"
+#include "anyobject.h"
+
+#include "../include/rt355.h"
+
+namespace {
+
+Vector3D vec(const double *p) { return Vector3D(p[0], p[1], p[2]); }
+Point3D pnt(const double *p) { return Point3D(p[0], p[1], p[2]); }
+
+// Write a 24-bit BMP the way Texture::Texture expects to read it (texture.h:54-78):
+// 54-byte header with width at 18 and height at 22, then width*height*3 bytes, B,G,R.
+std::string write_bmp(const rt355_texture &t, const std::string &dir, int id) {
+    std::string path = dir + "/rt355_tex_" + std::to_string(id) + ".bmp";
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return "";
+    unsigned char hdr[54];
+    memset(hdr, 0, sizeof hdr);
+    hdr[0] = 'B'; hdr[1] = 'M'; hdr[10] = 54; hdr[14] = 40; hdr[26] = 1; hdr[28] = 24;
+    memcpy(hdr + 18, &t.width, 4);
+    memcpy(hdr + 22, &t.height, 4);
+    fwrite(hdr, 1, 54, f);
+    size_t n = (size_t)t.width * t.height;
+    std::vector<unsigned char> bgr(n * 3);
+    for (size_t i = 0; i < n; i++) {
+        bgr[3 * i] = t.rgb[3 * i + 2];
+        bgr[3 * i + 1] = t.rgb[3 * i + 1];
+        bgr[3 * i + 2] = t.rgb[3 * i];
+    }
+    fwrite(bgr.data(), 1, bgr.size(), f);
+    fclose(f);
+    return path;
+}
+
+struct RefScene {
+    std::vector<AnyObject *> objs;
+    std::vector<int> kinds;
+    ~RefScene() {
+        for (AnyObject *o : objs) {
+            for (Texture *t : o->textures) delete t; // shared pointers are not used below
+            delete o;
+        }
+    }
+};
+
+// Build reference objects from a descriptor.  Returns false on I/O failure.
+bool build(const rt355_scene_desc *d, const char *tmpdir, RefScene &rs) {
+    std::vector<std::string> tex_paths(d->n_textures);
+    for (int i = 0; i < d->n_textures; i++) {
+        tex_paths[i] = write_bmp(d->textures[i], tmpdir ? tmpdir : "/tmp", i);
+        if (tex_paths[i].empty()) return false;
+    }
+    // Mesh's ctor reports a missing OBJ file on cout; keep the test output clean.
+    std::streambuf *old = std::cout.rdbuf();
+    std::ostringstream sink;
+    for (int i = 0; i < d->n_objects; i++) {
+        const rt355_object &o = d->objects[i];
+        Color clr(o.rgb[0], o.rgb[1], o.rgb[2]);
+        AnyObject *obj = nullptr;
+        if (o.type == RT355_OBJ_PLANE) {
+            obj = new Plane(pnt(o.p), vec(o.n), vec(o.n0), clr, o.ks);
+        } else if (o.type == RT355_OBJ_SPHERE) {
+            obj = new Sphere(pnt(o.p), o.radius, clr, vec(o.n0), vec(o.n1), vec(o.n2), o.ks);
+        } else {
+            std::cout.rdbuf(sink.rdbuf());
+            Mesh *m = new Mesh("/nonexistent/rt355.obj", Point3D(0, 0, 0), 1, o.ks);
+            std::cout.rdbuf(old);
+            m->clr = clr;
+            for (int k = 0; k < o.tri_count; k++) {
+                const rt355_triangle &t = d->triangles[o.tri_begin + k];
+                // what the OBJ face branch does, anyobject.h:625-636
+                Triangle tri(pnt(t.p0), pnt(t.p1), pnt(t.p2), o.ks);
+                tri.SetUV(Vector2D(t.uv0[0], t.uv0[1]), Vector2D(t.uv1[0], t.uv1[1]),
+                          Vector2D(t.uv2[0], t.uv2[1]));
+                tri.clr = m->clr;
+                m->triangles.push_back(tri);
+            }
+            obj = m;
+        }
+        obj->fresnel = o.fresnel;
+        obj->IOR = o.ior;
+        obj->texture_type = o.texture_type;
+        if (o.tex0 >= 0) obj->AddTexture(tex_paths[o.tex0], d->textures[o.tex0].sx, d->textures[o.tex0].sy);
+        if (o.tex1 >= 0) obj->AddTexture(tex_paths[o.tex1], d->textures[o.tex1].sx, d->textures[o.tex1].sy);
+        rs.objs.push_back(obj);
+        rs.kinds.push_back(o.type);
+    }
+    return true;
+}
+
+struct Cam { Point3D p_eye, p00; Vector3D n0, n1; double s_x, s_y; };
+
+// Scene::SetCamera (main.cpp:255-262), re-expressed
+Cam set_camera(const rt355_camera *c) {
+    Cam k;
+    Vector3D v_view = vec(c->v_view), v_up = vec(c->v_up);
+    k.p_eye = pnt(c->p_eye);
+    Vector3D n_view = Normalize(v_view);
+    Point3D p_center = k.p_eye + n_view * c->dist;
+    Vector3D v0 = CrossProduct(v_view, v_up);
+    k.n0 = Normalize(v0);
+    k.n1 = CrossProduct(k.n0, n_view);
+    k.p00 = p_center - k.n0 * (c->s_x / 2) - k.n1 * (c->s_y / 2);
+    k.s_x = c->s_x; k.s_y = c->s_y;
+    return k;
+}
+
+// CalcView (main.cpp:269-276), re-expressed
+View calc_view(const Cam &k, double x_per, double y_per) {
+    Point3D pp = k.p00 + k.n0 * (x_per * k.s_x) + k.n1 * (y_per * k.s_y);
+    Vector3D npe = Normalize(pp - k.p_eye);
+    return View(k.p_eye, npe);
+}
+
+// CalcSubPixel's closest-hit loop and shading call (main.cpp:65-91), re-expressed.  The
+// recursion at main.cpp:93-155 is inert for ks == 0, fresnel == 1.
+Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd) {
+    double t_min = FLT_MAX;
+    int object_index = 0;
+    Color cm0(0, 0, 0);
+    Point3D ph(0, 0, 0);
+    Vector3D nh(0, 0, 0);
+    bool no_border = true;
+    Vector2D UV(0, 0);
+    for (int i = 0; i < (int)objs.size(); i++) {
+        tuple<Color, double, Point3D, Vector3D, int> r = objs[i]->CalcIntersect(eye);
+        double t = get<1>(r);
+        if (t >= 0 && t < t_min) {
+            t_min = t; object_index = i;
+            cm0 = get<0>(r); ph = get<2>(r); nh = get<3>(r);
+            std::string kind = objs[i]->GetObjectType();
+            no_border = (kind == "Plane" || kind == "Mesh");
+            if (kind == "Mesh") UV = ((Mesh *)objs[i])->GetUV();
+        }
+    }
+    if (t_min != FLT_MAX)
+        return shd.shading(cm0, shd.ambient_color, ph, nh, eye, no_border, objs, object_index, UV, 0, 0);
+    return Color(0, 0, 0);
+}
+
+std::vector<light_src *> make_lights(const rt355_shader *sh) {
+    std::vector<light_src *> ls;
+    for (int i = 0; i < sh->n_lights; i++) {
+        const rt355_light &l = sh->lights[i];
+        light_src *p = new light_src(l.type, pnt(l.position), vec(l.direction), vec(l.color));
+        p->direction = vec(l.direction); // the descriptor holds the member as stored
+        ls.push_back(p);
+    }
+    return ls;
+}
+
+} // namespace
+
+extern "C" {
+
+int ref_render(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
+               const rt355_opts *opts, unsigned char *pixmap, const char *tmpdir) {
+    RefScene rs;
+    if (!build(d, tmpdir, rs)) return -1;
+    std::vector<light_src *> ls = make_lights(sh);
+    Shader shd(ls, Color(sh->ambient[0], sh->ambient[1], sh->ambient[2]),
+               Color(sh->specular[0], sh->specular[1], sh->specular[2]),
+               Color(sh->border[0], sh->border[1], sh->border[2]));
+    Cam k = set_camera(cam);
+    int W = opts->width, H = opts->height;
+    int y0 = opts->row_begin, y1 = opts->row_end;
+    if (y0 == 0 && y1 == 0) y1 = H;
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < W; x++) {
+            View eye = calc_view(k, (double)x / W, (double)y / H);
+            Color c = sub_pixel(eye, rs.objs, shd);
+            size_t i = ((size_t)y * W + x) * 3;
+            pixmap[i] = c.r; pixmap[i + 1] = c.g; pixmap[i + 2] = c.b;
+        }
+    for (light_src *l : ls) delete l;
+    return 0;
+}
+
+// objs[obj]->CalcIntersect(View(pe,npe)); out = t, ph[3], nh[3], uv[2]
+int ref_intersect(const rt355_scene_desc *d, int obj, const double *pe, const double *npe,
+                  double *out, const char *tmpdir) {
+    RefScene rs;
+    if (!build(d, tmpdir, rs)) return -1;
+    View eye(pnt(pe), vec(npe));
+    tuple<Color, double, Point3D, Vector3D, int> r = rs.objs[obj]->CalcIntersect(eye);
+    out[0] = get<1>(r);
+    Point3D ph = get<2>(r);
+    Vector3D nh = get<3>(r);
+    out[1] = ph.x; out[2] = ph.y; out[3] = ph.z;
+    out[4] = nh.x; out[5] = nh.y; out[6] = nh.z;
+    out[7] = out[8] = 0;
+    if (rs.kinds[obj] == RT355_OBJ_MESH && out[0] >= 0) {
+        Vector2D uv = ((Mesh *)rs.objs[obj])->GetUV();
+        out[7] = uv.x; out[8] = uv.y;
+    }
+    return 0;
+}
+
+// Many rays against one object without rebuilding it: rays = n x 6, out = n x 9
+int ref_intersect_many(const rt355_scene_desc *d, int obj, const double *rays, int n,
+                       double *out, const char *tmpdir) {
+    RefScene rs;
+    if (!build(d, tmpdir, rs)) return -1;
+    for (int i = 0; i < n; i++) {
+        const double *q = rays + 6 * i;
+        double *o = out + 9 * i;
+        View eye(pnt(q), vec(q + 3));
+        tuple<Color, double, Point3D, Vector3D, int> r = rs.objs[obj]->CalcIntersect(eye);
+        o[0] = get<1>(r);
+        Point3D ph = get<2>(r);
+        Vector3D nh = get<3>(r);
+        o[1] = ph.x; o[2] = ph.y; o[3] = ph.z;
+        o[4] = nh.x; o[5] = nh.y; o[6] = nh.z;
+        o[7] = o[8] = 0;
+        if (rs.kinds[obj] == RT355_OBJ_MESH && o[0] >= 0) {
+            Vector2D uv = ((Mesh *)rs.objs[obj])->GetUV();
+            o[7] = uv.x; o[8] = uv.y;
+        }
+    }
+    return 0;
+}
+
+// Color operators (color.h:33-51): op 0 `c*v`, 1 `c/v`, 2 `c+c2`, 3 `c*Vector3D`
+void ref_color_op(int op, const unsigned char *c, const unsigned char *c2, double v, double v2,
+                  double v3, unsigned char *out) {
+    Color a(c[0], c[1], c[2]), r = a;
+    if (op == 0) r = a * v;
+    else if (op == 1) r = a / v;
+    else if (op == 2) r = a + Color(c2[0], c2[1], c2[2]);
+    else if (op == 3) r = a * Vector3D(v, v2, v3);
+    out[0] = r.r; out[1] = r.g; out[2] = r.b;
+}
+
+// Texture::GetColorPlane (kind 0) / GetColorSphere (kind 1), texture.h:81-122
+int ref_texture(const rt355_texture *t, int kind, const double *ab, int n, unsigned char *out,
+                const char *tmpdir) {
+    std::string path = write_bmp(*t, tmpdir ? tmpdir : "/tmp", 9999);
+    if (path.empty()) return -1;
+    Texture tex(path, t->sx, t->sy);
+    for (int i = 0; i < n; i++) {
+        Color r = kind ? tex.GetColorSphere(ab[2 * i], ab[2 * i + 1]) : tex.GetColorPlane(ab[2 * i], ab[2 * i + 1]);
+        out[3 * i] = r.r; out[3 * i + 1] = r.g; out[3 * i + 2] = r.b;
+    }
+    return 0;
+}
+
+} // extern "C"

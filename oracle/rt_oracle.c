@@ -1,0 +1,475 @@
+/*
+ * rt_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, double-precision CPU restatement of the per-pixel render path of
+ * liz425/RayTracer (image_synthesis/main.cpp + headers), written from the algorithm,
+ * operation by operation, so that its frames are byte-identical to the reference's.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * HIP library never links or calls anything in this file.
+ *
+ * Parity pin: oracle/ref_harness.cpp compiles the reference's own headers and compares
+ * (tests/golden/ holds the derived vectors); the three frame hashes the reference
+ * main.cpp path produced are checked in tests/test_oracle_golden.py.
+ *
+ * Every function cites the reference lines (relative to image_synthesis/) it follows.
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (no -ffast-math: the
+ * operation order and roundings below are the contract).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/rt355.h"
+
+/* texture.h:17 defines PI first; shader.h:15-17 and main.cpp:23-25 are #ifndef guarded,
+ * so 3.1415927 is the value everywhere. */
+#define REF_PI 3.1415927
+
+typedef struct { double x, y, z; } v3;
+typedef struct { unsigned char r, g, b; } col;
+
+/* ---- vector3D.h ------------------------------------------------------------------------- */
+static v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }   /* vector3D.h:33,118 */
+static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }   /* :38,113,123 */
+static v3 vmul(v3 a, double s) { return V(a.x * s, a.y * s, a.z * s); }     /* :46 */
+static v3 vdiv(v3 a, double s) { return V(a.x / s, a.y / s, a.z / s); }     /* :42 */
+static double vlen(v3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); } /* :50 */
+static double dot(v3 u, v3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }  /* :90 */
+static v3 cross(v3 u, v3 v) {                                                /* :94 */
+    return V(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+static v3 normalize(v3 v) {                                                  /* :79-88, :55-63 */
+    double l = vlen(v);
+    if (l != 0) return vdiv(v, l);
+    return v;
+}
+static v3 from3(const double *p) { return V(p[0], p[1], p[2]); }
+
+/* ---- color.h ------------------------------------------------------------------------------ */
+/* Color(char,char,char) (color.h:25) receives double or int expressions.  On x86-64 the
+ * double->char conversion is cvttsd2si to 32 bits followed by a byte truncation: toward
+ * zero, wrap mod 256, out-of-range/NaN -> 0x80000000 -> 0. */
+static unsigned char q8(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return 0;
+    return (unsigned char)(int32_t)x;
+}
+static col C(unsigned char r, unsigned char g, unsigned char b) { col c = {r, g, b}; return c; }
+static col cmul(col c, double v) { return C(q8(c.r * v), q8(c.g * v), q8(c.b * v)); }          /* :33 */
+static col cmulv(col c, v3 v) { return C(q8(c.r * v.x), q8(c.g * v.y), q8(c.b * v.z)); }       /* :37 */
+static col cdivd(col c, double v) { return C(q8(c.r / v), q8(c.g / v), q8(c.b / v)); }         /* :41 */
+static col cadd(col a, col b) {                                                                 /* :45 */
+    return C((unsigned char)(a.r + b.r), (unsigned char)(a.g + b.g), (unsigned char)(a.b + b.b));
+}
+
+/* x86 (int)double as the reference's `(int)x` casts compile (texture.h:92-97, shader.h:253). */
+static int trunc_i32(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return INT32_MIN;
+    return (int32_t)x;
+}
+
+/* ---- flattened scene ------------------------------------------------------------------------ */
+typedef struct {
+    v3 p0, p1, p2, normal, p_center;
+    double uv0[2], uv1[2], uv2[2];
+} otri;
+
+typedef struct {
+    const rt355_scene_desc *d;
+    otri *tris;
+} oscene;
+
+/* Triangle ctor, anyobject.h:456-461 */
+static void tri_setup(const rt355_triangle *t, otri *o) {
+    o->p0 = from3(t->p0); o->p1 = from3(t->p1); o->p2 = from3(t->p2);
+    o->normal = normalize(cross(vsub(o->p1, o->p0), vsub(o->p2, o->p0)));
+    o->p_center = V((o->p0.x + o->p1.x + o->p2.x) / 3.0, (o->p0.y + o->p1.y + o->p2.y) / 3.0,
+                    (o->p0.z + o->p1.z + o->p2.z) / 3.0);
+    memcpy(o->uv0, t->uv0, sizeof o->uv0);
+    memcpy(o->uv1, t->uv1, sizeof o->uv1);
+    memcpy(o->uv2, t->uv2, sizeof o->uv2);
+}
+
+typedef struct { v3 pe, npe; } ray;
+/* View(Point3D, Vector3D) normalises its direction (view.h:23) */
+static ray mkview(v3 pe, v3 npe) { ray r; r.pe = pe; r.npe = normalize(npe); return r; }
+
+typedef struct {
+    double t;     /* -1 = miss (anyobject.h:81,151,500,520,664) */
+    v3 ph, nh;
+    double uvx, uvy; /* Mesh::UV_hitpoint (anyobject.h:655) */
+} hit;
+
+/* Plane::CalcIntersect, anyobject.h:69-87 (outside == 0 on every call of this path) */
+static hit plane_isect(const rt355_object *o, ray e) {
+    hit h; memset(&h, 0, sizeof h);
+    v3 ni = from3(o->n), pi = from3(o->p);
+    int outside = (dot(ni, vsub(e.pe, pi)) <= 0) ? -1 : 1;
+    if (dot(ni, e.npe) >= 0) { h.t = -1; return h; }
+    h.t = -dot(ni, vsub(e.pe, pi)) / dot(ni, e.npe);
+    h.ph = vadd(e.pe, vmul(e.npe, h.t));
+    h.nh = vmul(ni, outside);
+    return h;
+}
+
+/* Sphere::CalcIntersect, anyobject.h:128-158 */
+static hit sphere_isect(const rt355_object *o, ray e) {
+    hit h; memset(&h, 0, sizeof h);
+    v3 c = from3(o->p);
+    double r = o->radius;
+    v3 ec = vsub(e.pe, c);
+    int outside = (dot(ec, ec) - r * r <= -0.00001) ? -1 : 1;
+    double B = dot(e.npe, vsub(c, e.pe));
+    double Cc = dot(ec, ec) - r * r;
+    double delta = B * B - Cc;
+    if (delta < 0) { h.t = -1; return h; }
+    h.t = B - outside * sqrt(delta);
+    h.ph = vadd(e.pe, vmul(e.npe, h.t));
+    h.nh = vmul(normalize(vsub(h.ph, c)), outside);
+    return h;
+}
+
+/* Triangle::CalcIntersect, anyobject.h:475-522; u,v returned for GetUV (:524-526) */
+static hit tri_isect(const otri *t, ray e, double *u_out, double *v_out) {
+    hit h; memset(&h, 0, sizeof h);
+    int outside = (dot(t->normal, vsub(e.pe, t->p_center)) <= 0) ? -1 : 1;
+    if (dot(t->normal, e.npe) >= 0) { h.t = -1; return h; }
+    double tt = -dot(t->normal, vsub(e.pe, t->p_center)) / dot(t->normal, e.npe);
+    if ((outside < 0 && tt > 0) || (tt < 0)) { h.t = -1; return h; }
+    v3 ph = vadd(e.pe, vmul(e.npe, tt));
+    v3 AA = cross(vsub(t->p1, t->p0), vsub(t->p2, t->p0));
+    v3 A1 = cross(vsub(t->p2, ph), vsub(t->p0, ph));
+    v3 A2 = cross(vsub(t->p0, ph), vsub(t->p1, ph));
+    double u = (AA.x != 0) ? A1.x / AA.x : ((AA.y != 0) ? A1.y / AA.y : A1.z / AA.z);
+    double v = (AA.x != 0) ? A2.x / AA.x : ((AA.y != 0) ? A2.y / AA.y : A2.z / AA.z);
+    if (u >= 0 && v >= 0 && (u + v) <= 1) {
+        h.t = tt; h.ph = ph; h.nh = vmul(t->normal, outside);
+        *u_out = u; *v_out = v;
+        return h;
+    }
+    h.t = -1;
+    return h;
+}
+
+/* Mesh::CalcIntersect, anyobject.h:646-666 */
+static hit mesh_isect(const oscene *s, const rt355_object *o, ray e) {
+    double t_min = FLT_MAX;
+    hit best; memset(&best, 0, sizeof best);
+    for (int i = 0; i < o->tri_count; i++) {
+        const otri *t = &s->tris[o->tri_begin + i];
+        double u = 0, v = 0;
+        hit h = tri_isect(t, e, &u, &v);
+        if (h.t >= 0 && h.t < t_min) {
+            t_min = h.t;
+            best = h;
+            /* Triangle::GetUV, :524-526: UV_p0*(1-u-v) + UV_p1*u + UV_p2*v */
+            double w = 1 - u - v;
+            best.uvx = t->uv0[0] * w + t->uv1[0] * u + t->uv2[0] * v;
+            best.uvy = t->uv0[1] * w + t->uv1[1] * u + t->uv2[1] * v;
+        }
+    }
+    if (t_min > 0 && t_min != FLT_MAX) return best;
+    memset(&best, 0, sizeof best);
+    best.t = -1;
+    return best;
+}
+
+static hit obj_isect(const oscene *s, int i, ray e) {
+    const rt355_object *o = &s->d->objects[i];
+    if (o->type == RT355_OBJ_PLANE) return plane_isect(o, e);
+    if (o->type == RT355_OBJ_SPHERE) return sphere_isect(o, e);
+    return mesh_isect(s, o, e);
+}
+
+/* ---- texture.h ------------------------------------------------------------------------------ */
+static col texel(const rt355_texture *t, int idx) {
+    return C(t->rgb[3 * idx], t->rgb[3 * idx + 1], t->rgb[3 * idx + 2]);
+}
+/* shared tail of GetColorSphere / GetColorPlane, texture.h:92-103 / 110-121 */
+static col bilinear(const rt355_texture *t, double x, double y) {
+    int ix = trunc_i32(x), iy = trunc_i32(y);
+    double u = x - ix, v = y - iy;
+    int W = t->width, H = t->height;
+    int pre00 = iy % H * W + ix % W;
+    int pre01 = (iy + 1) % H * W + ix % W;
+    int pre11 = (iy + 1) % H * W + (ix + 1) % W;
+    int pre10 = iy % H * W + (ix + 1) % W;
+    col c00 = texel(t, pre00), c01 = texel(t, pre01), c11 = texel(t, pre11), c10 = texel(t, pre10);
+    col a = cmul(cmul(c00, 1 - u), 1 - v);
+    col b = cmul(cmul(c01, 1 - u), v);
+    col c = cmul(cmul(c11, u), v);
+    col d = cmul(cmul(c10, u), 1 - v);
+    return cadd(cadd(cadd(a, b), c), d);
+}
+static col tex_sphere(const rt355_texture *t, double theta, double phi) { /* texture.h:81-105 */
+    double x = theta / (2 * REF_PI) * t->width / t->sx;
+    double y = phi / REF_PI * t->height / t->sy;
+    return bilinear(t, x, y);
+}
+static col tex_plane(const rt355_texture *t, double x, double y) {        /* texture.h:107-122 */
+    return bilinear(t, x * t->width, y * t->height);
+}
+
+/* Shader::TextureMapping, shader.h:196-288 (normal map off, shader.h:23) */
+static void texture_mapping(const oscene *s, const rt355_object *o, v3 ph, double uvx, double uvy,
+                            col *cm0, col *cm1) {
+    const rt355_texture *t0 = &s->d->textures[o->tex0], *t1 = &s->d->textures[o->tex1];
+    if (o->type == RT355_OBJ_SPHERE) {
+        v3 c = from3(o->p);
+        double x = dot(from3(o->n0), vsub(ph, c)) / o->radius;
+        double y = dot(from3(o->n1), vsub(ph, c)) / o->radius;
+        double z = dot(from3(o->n2), vsub(ph, c)) / o->radius;
+        double phi = REF_PI - acos(z);
+        double theta = 0;
+        if (z != 1 && z != -1) {
+            /* `long double sss`, and acos(long double) is acosl under <cmath> (shader.h:216-222) */
+            long double sss = y / sqrt(1 - z * z);
+            if (sss > -1 && sss < 1) theta = (double)acosl(sss);
+            else if (sss == 1) theta = 0;
+            else if (sss == -1) theta = REF_PI;
+            else theta = 0;
+        }
+        if (x < 0) theta = 2 * REF_PI - theta;
+        *cm0 = tex_sphere(t0, theta, phi);
+        *cm1 = tex_sphere(t1, theta, phi);
+    } else if (o->type == RT355_OBJ_PLANE) {
+        v3 pi = from3(o->p), n0 = from3(o->n0);
+        v3 n1 = cross(n0, from3(o->n)); /* Plane ctor, anyobject.h:57 */
+        double x = dot(n0, vsub(ph, pi)) / t0->sx;
+        x = x - trunc_i32(x);
+        double y = dot(n1, vsub(ph, pi)) / t0->sy;
+        y = y - trunc_i32(y);
+        x = (x < 0) ? x + 1 : x;
+        y = (y < 0) ? y + 1 : y;
+        *cm0 = tex_plane(t0, x, y);
+        *cm1 = tex_plane(t1, x, y);
+    } else {
+        *cm0 = tex_plane(t0, uvx, uvy);
+        *cm1 = tex_plane(t1, uvx, uvy);
+    }
+}
+
+/* ---- shader.h --------------------------------------------------------------------------------- */
+typedef struct {
+    const oscene *s;
+    const rt355_shader *sh;
+    uint64_t shadow_rays;
+} octx;
+
+static col calc_diffuse(const rt355_light *L, col cm0, col cm1, v3 nh, v3 nhl) { /* shader.h:324-338 */
+    double t = (dot(nh, vmul(nhl, -1)) + 1) / 2.0;
+    if (L->type == 2) t = t * ((dot(from3(L->direction), nhl) + 1) / 2.0);
+    v3 lc = vmul(from3(L->color), t);
+    return cadd(cmulv(cm0, lc), cmulv(cm1, vsub(V(1, 1, 1), lc)));
+}
+static col calc_specular(const rt355_shader *sh, const rt355_light *L, col clr, v3 nh, ray eye,
+                         v3 nhl) {                                                /* shader.h:340-376 */
+    v3 reh = normalize(vsub(eye.npe, vmul(nh, 2 * dot(nh, eye.npe))));
+    double s = dot(vmul(nhl, -1), reh);
+    s = (s > 0) ? s : 0;
+    s = pow(s, 25);
+    if (L->type == 2) s = s * ((dot(from3(L->direction), nhl) + 1) / 2.0);
+    return cadd(cmul(clr, 1 - s), cmul(C(sh->specular[0], sh->specular[1], sh->specular[2]), s));
+}
+static col calc_border(const rt355_shader *sh, col clr, v3 ph, v3 nh, ray eye) {   /* shader.h:378-387 */
+    double b = 1 - dot(normalize(vsub(eye.pe, ph)), nh);
+    double mn = 0.8, mx = 0.9;
+    b = (b - mn) / (mx - mn);
+    b = (b > 1) ? 1 : ((b < 0) ? 0 : b);
+    return cadd(cmul(clr, 1 - b), cmul(C(sh->border[0], sh->border[1], sh->border[2]), b));
+}
+static col calc_shadow(octx *cx, const rt355_light *L, col clr, v3 ph, v3 nh, v3 nhl) { /* shader.h:393-433 */
+    double shd = 1;
+    v3 nlh = vmul(nhl, -1);
+    if (dot(nh, nlh) <= 0) {
+        shd = 0.5;
+    } else {
+        int n = cx->s->d->n_objects;
+        double t_min = FLT_MAX;
+        ray sr = mkview(ph, nlh);
+        cx->shadow_rays++;
+        for (int i = 0; i < n; i++) {
+            hit h = obj_isect(cx->s, i, sr);
+            if (h.t >= 0 && h.t < t_min) t_min = h.t;
+        }
+        double Ld = vlen(vsub(from3(L->position), ph));
+        if (t_min > 0 && t_min < Ld) shd = t_min / Ld;
+    }
+    if (L->type == 2) shd = shd * ((dot(from3(L->direction), nhl) + 1) / 2.0);
+    const rt355_shader *sh = cx->sh;
+    return cadd(cmul(clr, shd), cmul(C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), 1 - shd));
+}
+
+/* Shader::shading, shader.h:42-96 */
+static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_border, int obj,
+                   double uvx, double uvy) {
+    const rt355_object *o = &cx->s->d->objects[obj];
+    const rt355_shader *sh = cx->sh;
+    col clr_sum = C(0, 0, 0);
+    if (o->texture_type == 1) texture_mapping(cx->s, o, ph, uvx, uvy, &cm0, &cm1);
+    for (int k = 0; k < sh->n_lights; k++) {
+        const rt355_light *L = &sh->lights[k];
+        v3 nhl;
+        if (L->type == 0) nhl = from3(L->direction);
+        else nhl = normalize(vsub(ph, from3(L->position)));
+        col clr = calc_diffuse(L, cm0, cm1, nh, nhl);
+        clr = calc_specular(sh, L, clr, nh, eye, nhl);
+        if (!no_border) clr = calc_border(sh, clr, ph, nh, eye);
+        clr = calc_shadow(cx, L, clr, ph, nh, nhl);
+        clr_sum = cadd(cmul(cdivd(clr_sum, k + 1.0), k), cdivd(clr, k + 1.0));
+    }
+    return clr_sum;
+}
+
+/* CalcSubPixel, main.cpp:42-91 with reflection_times=0, outside=1; the recursion at
+ * :93-155 is inert because every object has ks == 0 and fresnel == 1. */
+static col calc_subpixel(octx *cx, ray eye) {
+    int n = cx->s->d->n_objects;
+    double t_min = FLT_MAX;
+    hit best; memset(&best, 0, sizeof best);
+    int idx = 0, no_border = 1;
+    for (int i = 0; i < n; i++) {
+        hit h = obj_isect(cx->s, i, eye);
+        if (h.t >= 0 && h.t < t_min) {
+            t_min = h.t; idx = i; best = h;
+            no_border = (cx->s->d->objects[i].type != RT355_OBJ_SPHERE);
+        }
+    }
+    if (t_min != FLT_MAX) {
+        const rt355_object *o = &cx->s->d->objects[idx];
+        const rt355_shader *sh = cx->sh;
+        return shading(cx, C(o->rgb[0], o->rgb[1], o->rgb[2]),
+                       C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), best.ph, best.nh, eye,
+                       no_border, idx, best.uvx, best.uvy);
+    }
+    return C(0, 0, 0);
+}
+
+typedef struct { v3 p_eye, n0, n1, p00; double s_x, s_y; } ocam;
+/* Scene::SetCamera, main.cpp:255-262 */
+static ocam set_camera(const rt355_camera *c) {
+    ocam o;
+    v3 v_view = from3(c->v_view), v_up = from3(c->v_up);
+    o.p_eye = from3(c->p_eye);
+    v3 n_view = normalize(v_view);
+    v3 p_center = vadd(o.p_eye, vmul(n_view, c->dist));
+    v3 v0 = cross(v_view, v_up);
+    o.n0 = normalize(v0);
+    o.n1 = cross(o.n0, n_view);
+    o.p00 = vsub(vsub(p_center, vmul(o.n0, c->s_x / 2)), vmul(o.n1, c->s_y / 2));
+    o.s_x = c->s_x; o.s_y = c->s_y;
+    return o;
+}
+/* CalcView, main.cpp:269-276 (Normalize at :272, again in the View ctor at view.h:23) */
+static ray calc_view(const ocam *c, double x_per, double y_per) {
+    v3 pp = vadd(vadd(c->p00, vmul(c->n0, x_per * c->s_x)), vmul(c->n1, y_per * c->s_y));
+    v3 npe = normalize(vsub(pp, c->p_eye));
+    return mkview(c->p_eye, npe);
+}
+
+static int oscene_init(oscene *s, const rt355_scene_desc *d) {
+    s->d = d;
+    s->tris = NULL;
+    if (d->n_triangles > 0) {
+        s->tris = (otri *)malloc(sizeof(otri) * (size_t)d->n_triangles);
+        if (!s->tris) return -1;
+        for (int i = 0; i < d->n_triangles; i++) tri_setup(&d->triangles[i], &s->tris[i]);
+    }
+    return 0;
+}
+
+/* ---- exported entry points ------------------------------------------------------------------ */
+
+/* setPixels + CalcPixel with alias == 0, main.cpp:339-376, 326-332.
+ * `stride` > 1 renders only pixels with x % stride == 0 and y % stride == 0 (the rays
+ * are the same as the full frame's; other pixels are left untouched) -- used to time a
+ * bounded sample.  n_threads <= 0 = all cores; rows are interleaved over threads. */
+int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
+                     const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats,
+                     int n_threads, int stride) {
+    if (!d || !cam || !sh || !opts || !pixmap) return RT355_ERR_ARG;
+    if (opts->alias != 0) return RT355_ERR_UNSUPPORTED;
+    oscene s;
+    if (oscene_init(&s, d)) return RT355_ERR_NOMEM;
+    ocam c = set_camera(cam);
+    int W = opts->width, H = opts->height;
+    int y0 = opts->row_begin, y1 = opts->row_end;
+    if (y0 == 0 && y1 == 0) y1 = H;
+    if (stride < 1) stride = 1;
+    uint64_t prim = 0, shad = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    (void)n_threads;
+#pragma omp parallel for schedule(static, 1) reduction(+ : prim, shad)
+    for (int y = y0; y < y1; y++) {
+        if (y % stride) continue;
+        octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0;
+        for (int x = 0; x < W; x += stride) {
+            ray eye = calc_view(&c, (double)x / W, (double)y / H);
+            col clr = calc_subpixel(&cx, eye);
+            size_t i = ((size_t)y * W + x) * 3;
+            pixmap[i] = clr.r; pixmap[i + 1] = clr.g; pixmap[i + 2] = clr.b;
+            prim++;
+        }
+        shad += cx.shadow_rays;
+    }
+    free(s.tris);
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->primary_rays = prim;
+        stats->shadow_rays = shad;
+    }
+    return RT355_OK;
+}
+
+/* Known-answer probes (one call = one reference function). */
+
+/* Camera ray of pixel (x,y): out[0..2] = pe, out[3..5] = npe. */
+void rt_oracle_view(const rt355_camera *cam, int W, int H, int x, int y, double *out) {
+    ocam c = set_camera(cam);
+    ray e = calc_view(&c, (double)x / W, (double)y / H);
+    out[0] = e.pe.x; out[1] = e.pe.y; out[2] = e.pe.z;
+    out[3] = e.npe.x; out[4] = e.npe.y; out[5] = e.npe.z;
+}
+
+/* objs[obj]->CalcIntersect(View(pe,npe)): out = t, ph[3], nh[3], uv[2] */
+int rt_oracle_intersect(const rt355_scene_desc *d, int obj, const double *pe, const double *npe,
+                        double *out) {
+    oscene s;
+    if (oscene_init(&s, d)) return RT355_ERR_NOMEM;
+    hit h = obj_isect(&s, obj, mkview(from3(pe), from3(npe)));
+    out[0] = h.t; out[1] = h.ph.x; out[2] = h.ph.y; out[3] = h.ph.z;
+    out[4] = h.nh.x; out[5] = h.nh.y; out[6] = h.nh.z; out[7] = h.uvx; out[8] = h.uvy;
+    free(s.tris);
+    return RT355_OK;
+}
+
+/* Color operators: op 0 `c*v`, 1 `c/v`, 2 `c+c2`, 3 `c*Vector3D(v,v2,v3)` */
+void rt_oracle_color_op(int op, const unsigned char *c, const unsigned char *c2, double v, double v2,
+                        double v3_, unsigned char *out) {
+    col a = C(c[0], c[1], c[2]), r = a;
+    if (op == 0) r = cmul(a, v);
+    else if (op == 1) r = cdivd(a, v);
+    else if (op == 2) r = cadd(a, C(c2[0], c2[1], c2[2]));
+    else if (op == 3) r = cmulv(a, V(v, v2, v3_));
+    out[0] = r.r; out[1] = r.g; out[2] = r.b;
+}
+
+/* Texture::GetColorPlane (kind 0) / GetColorSphere (kind 1) */
+void rt_oracle_texture(const rt355_texture *t, int kind, double a, double b, unsigned char *out) {
+    col r = kind ? tex_sphere(t, a, b) : tex_plane(t, a, b);
+    out[0] = r.r; out[1] = r.g; out[2] = r.b;
+}
+
+/* FNV-1a 64 over a byte buffer: the frame hash quoted for reference frames. */
+uint64_t rt_oracle_fnv1a64(const unsigned char *p, uint64_t n) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (uint64_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ULL; }
+    return h;
+}

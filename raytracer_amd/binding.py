@@ -1,0 +1,253 @@
+"""ctypes/numpy mirror of include/rt355.h.
+
+Host-side scene containers laid out exactly as the C ABI expects, so a scene built in
+Python (tests, benchmark) is handed to the HIP library -- or to the CPU checker -- without
+copies.  Names follow the reference's scene vocabulary (objects, triangles, textures,
+lights; image_synthesis/anyobject.h, light.h, texture.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Sequence
+
+import numpy as np
+
+OBJ_PLANE, OBJ_SPHERE, OBJ_MESH = 0, 1, 2
+MODE_FAST, MODE_BRUTE = 0, 1
+
+ERR = {0: "OK", -1: "ERR_ARG", -2: "ERR_UNSUPPORTED", -3: "ERR_DEVICE", -4: "ERR_NOMEM"}
+
+# struct rt355_object (184 bytes)
+OBJECT_DTYPE = np.dtype(
+    {
+        "names": ["p", "n", "n0", "n1", "n2", "radius", "ks", "fresnel", "ior", "type",
+                  "texture_type", "tex0", "tex1", "tri_begin", "tri_count", "rgb", "pad_"],
+        "formats": [("f8", 3), ("f8", 3), ("f8", 3), ("f8", 3), ("f8", 3), "f8", "f8", "f8", "f8",
+                    "i4", "i4", "i4", "i4", "i4", "i4", ("u1", 3), ("u1", 5)],
+        "offsets": [0, 24, 48, 72, 96, 120, 128, 136, 144, 152, 156, 160, 164, 168, 172, 176, 179],
+        "itemsize": 184,
+    }
+)
+# struct rt355_light (80 bytes)
+LIGHT_DTYPE = np.dtype(
+    {
+        "names": ["position", "direction", "color", "type", "pad_"],
+        "formats": [("f8", 3), ("f8", 3), ("f8", 3), "i4", "i4"],
+        "offsets": [0, 24, 48, 72, 76],
+        "itemsize": 80,
+    }
+)
+
+
+class CTexture(C.Structure):
+    _fields_ = [("rgb", C.c_void_p), ("sx", C.c_double), ("sy", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class CSceneDesc(C.Structure):
+    _fields_ = [("objects", C.c_void_p), ("n_objects", C.c_int32), ("pad0_", C.c_int32),
+                ("triangles", C.c_void_p), ("n_triangles", C.c_int32), ("pad1_", C.c_int32),
+                ("textures", C.c_void_p), ("n_textures", C.c_int32), ("pad2_", C.c_int32)]
+
+
+class CCamera(C.Structure):
+    _fields_ = [("v_up", C.c_double * 3), ("v_view", C.c_double * 3), ("p_eye", C.c_double * 3),
+                ("dist", C.c_double), ("s_x", C.c_double), ("s_y", C.c_double)]
+
+
+class CShader(C.Structure):
+    _fields_ = [("lights", C.c_void_p), ("n_lights", C.c_int32), ("ambient", C.c_uint8 * 3),
+                ("specular", C.c_uint8 * 3), ("border", C.c_uint8 * 3), ("pad_", C.c_uint8 * 3)]
+
+
+class COpts(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("alias", C.c_int32),
+                ("row_begin", C.c_int32), ("row_end", C.c_int32), ("mode", C.c_int32)]
+
+
+class CStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("pair_tests", C.c_uint64), ("exact_tests", C.c_uint64),
+                ("overflow_rays", C.c_uint64), ("ms_device", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+assert C.sizeof(CTexture) == 32 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
+assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 24 and C.sizeof(CStats) == 48
+
+
+def _normalize(v: Sequence[float]):
+    """Normalize() of image_synthesis/vector3D.h:79-88, same operation order."""
+    x, y, z = float(v[0]), float(v[1]), float(v[2])
+    l = math.sqrt(x * x + y * y + z * z)
+    if l != 0:
+        return (x / l, y / l, z / l)
+    return (x, y, z)
+
+
+def rgb_of(clr) -> tuple:
+    """Color(unsigned int) of color.h:27-31, or a 3-sequence of bytes."""
+    if isinstance(clr, int):
+        return ((clr & 0xFF0000) >> 16, (clr & 0xFF00) >> 8, clr & 0xFF)
+    return tuple(int(c) & 0xFF for c in clr)
+
+
+@dataclass
+class Texture:
+    """A loaded Texture (texture.h:23-79): rgb is (height, width, 3) uint8 in the
+    reference's in-memory order (row 0 = bottom row of the BMP)."""
+    rgb: np.ndarray
+    sx: float = 1.0
+    sy: float = 1.0
+
+
+@dataclass
+class Scene:
+    """Scene::objs (main.cpp:229) flattened: objects in list order, the triangles of all
+    meshes, and the textures they refer to."""
+    objects: List[np.void] = field(default_factory=list)
+    triangles: List[np.ndarray] = field(default_factory=list)  # each (n,15) float64
+    textures: List[Texture] = field(default_factory=list)
+    _n_tri: int = 0
+
+    # -- builders mirroring the reference constructors --------------------------------
+    def _new(self, kind, rgb, ks=0.0):
+        o = np.zeros((), dtype=OBJECT_DTYPE)
+        o["type"] = kind
+        o["rgb"] = rgb_of(rgb)
+        o["ks"] = ks
+        o["fresnel"] = 1.0
+        o["ior"] = 1.0
+        o["tex0"] = o["tex1"] = -1
+        o["n0"] = (1, 0, 0); o["n1"] = (0, 1, 0); o["n2"] = (0, 0, 1)
+        return o
+
+    def add_plane(self, pi, ni, n0, clr, ks=0.0):
+        """Plane(Point3D pi, Vector3D ni, Vector3D n0, Color clr, double ks) anyobject.h:55"""
+        o = self._new(OBJ_PLANE, clr, ks)
+        o["p"] = pi; o["n"] = ni; o["n0"] = n0
+        self.objects.append(o)
+        return len(self.objects) - 1
+
+    def add_sphere(self, center, radius, clr, n0=(1, 0, 0), n1=(0, 1, 0), n2=(0, 0, 1), ks=0.0):
+        """Sphere(Point3D, double radius, Color, Vector3D n0, n1, n2, double ks) anyobject.h:113"""
+        o = self._new(OBJ_SPHERE, clr, ks)
+        o["p"] = center; o["radius"] = radius
+        o["n0"] = n0; o["n1"] = n1; o["n2"] = n2
+        self.objects.append(o)
+        return len(self.objects) - 1
+
+    def add_mesh(self, tris: np.ndarray, clr=(150, 200, 110), ks=0.0):
+        """A Mesh (anyobject.h:534-675) given as (n,15) float64 rows
+        p0 p1 p2 uv0 uv1 uv2; default colour as Mesh::clr (anyobject.h:536)."""
+        tris = np.ascontiguousarray(tris, dtype=np.float64).reshape(-1, 15)
+        o = self._new(OBJ_MESH, clr, ks)
+        o["tri_begin"] = self._n_tri
+        o["tri_count"] = len(tris)
+        self._n_tri += len(tris)
+        self.triangles.append(tris)
+        self.objects.append(o)
+        return len(self.objects) - 1
+
+    def add_texture(self, obj: int, rgb: np.ndarray, sx=1.0, sy=1.0):
+        """AnyObject::AddTexture (anyobject.h:32-35); the first call sets textures[0], the
+        second textures[1]."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        self.textures.append(Texture(rgb, float(sx), float(sy)))
+        tid = len(self.textures) - 1
+        o = self.objects[obj]
+        if o["tex0"] < 0:
+            o["tex0"] = tid
+        elif o["tex1"] < 0:
+            o["tex1"] = tid
+        else:
+            raise ValueError("only textures[0] and textures[1] are used on this path")
+        return tid
+
+    def set_texture_type(self, obj: int, texture_type: int):
+        self.objects[obj]["texture_type"] = texture_type
+
+    # -- C view ------------------------------------------------------------------------
+    def pack(self) -> "PackedScene":
+        return PackedScene(self)
+
+    @property
+    def n_primitives(self) -> int:
+        return sum(int(o["tri_count"]) if o["type"] == OBJ_MESH else 1 for o in self.objects)
+
+
+class PackedScene:
+    """Owns the contiguous arrays a CSceneDesc points into."""
+
+    def __init__(self, s: Scene):
+        self.objects = np.array(s.objects, dtype=OBJECT_DTYPE) if s.objects else np.zeros(0, OBJECT_DTYPE)
+        self.triangles = (np.ascontiguousarray(np.concatenate(s.triangles, axis=0))
+                          if s.triangles else np.zeros((0, 15), np.float64))
+        self.tex_arrays = [np.ascontiguousarray(t.rgb) for t in s.textures]
+        self.ctex = (CTexture * max(1, len(s.textures)))()
+        for i, t in enumerate(s.textures):
+            self.ctex[i].rgb = self.tex_arrays[i].ctypes.data
+            self.ctex[i].sx, self.ctex[i].sy = t.sx, t.sy
+            self.ctex[i].height, self.ctex[i].width = t.rgb.shape[0], t.rgb.shape[1]
+        d = CSceneDesc()
+        d.objects = self.objects.ctypes.data if len(self.objects) else None
+        d.n_objects = len(self.objects)
+        d.triangles = self.triangles.ctypes.data if len(self.triangles) else None
+        d.n_triangles = len(self.triangles)
+        d.textures = C.addressof(self.ctex) if s.textures else None
+        d.n_textures = len(s.textures)
+        self.desc = d
+
+
+def light_src(type_: int, position, direction, color=(1, 1, 1)) -> np.void:
+    """light_src(int type, Point3D position, Vector3D direction, Vector3D color), light.h:27-32:
+    the stored direction is Normalize(direction_in)."""
+    l = np.zeros((), dtype=LIGHT_DTYPE)
+    l["type"] = type_
+    l["position"] = position
+    l["direction"] = _normalize(direction)
+    l["color"] = color
+    return l
+
+
+class Shader:
+    """Shader(vector<light_src*>, Color ambient, Color specular, Color border), shader.h:32."""
+
+    def __init__(self, lights, ambient=0x000000, specular=0xDDDDDD, border=0x000000):
+        self.lights = np.array(list(lights), dtype=LIGHT_DTYPE) if len(lights) else np.zeros(0, LIGHT_DTYPE)
+        c = CShader()
+        c.lights = self.lights.ctypes.data if len(self.lights) else None
+        c.n_lights = len(self.lights)
+        c.ambient[:] = rgb_of(ambient)
+        c.specular[:] = rgb_of(specular)
+        c.border[:] = rgb_of(border)
+        self.c = c
+
+
+def camera(p_eye=(0, -20, 0), v_view=(0, 1, 0), v_up=(0, 0, 1), dist=10.0, width=800, height=600,
+           s_x=None, s_y=None) -> CCamera:
+    """The camera main() sets up (main.cpp:529-541): s_x = dist*4*width/height, s_y = dist*4."""
+    c = CCamera()
+    c.p_eye[:] = p_eye; c.v_view[:] = v_view; c.v_up[:] = v_up
+    c.dist = dist
+    c.s_x = dist * 4.0 * width / height if s_x is None else s_x
+    c.s_y = dist * 4 if s_y is None else s_y
+    return c
+
+
+def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_FAST) -> COpts:
+    return COpts(width, height, alias, row_begin, row_end, mode)
+
+
+def fnv1a64(buf) -> int:
+    """FNV-1a 64 over a byte buffer (offset 0xcbf29ce484222325, prime 0x100000001b3).
+    Pure Python: meant for small frames; the CPU checker exports a C version for 4K ones."""
+    h = 0xCBF29CE484222325
+    for b in bytes(memoryview(buf)):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h

@@ -1,0 +1,256 @@
+"""Scene builders: the reference's default scene and the synthetic benchmark scenes.
+
+Everything is generated from fixed seeds with SplitMix64 so the same bytes are produced
+on every machine (no dependence on numpy's generator versions).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .binding import OBJECT_DTYPE, OBJ_SPHERE, Scene, Shader, camera, light_src
+
+_M64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.s = seed & _M64
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & _M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        return z ^ (z >> 31)
+
+    def uniform(self, lo=0.0, hi=1.0) -> float:
+        return lo + (hi - lo) * ((self.next() >> 11) * (1.0 / (1 << 53)))
+
+    def array(self, n: int) -> np.ndarray:
+        """n uniform doubles in [0,1), vectorised SplitMix64."""
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            z = np.uint64(self.s) + idx * np.uint64(0x9E3779B97F4A7C15)
+            self.s = int(z[-1]) if n else self.s
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        return (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+# ---- the reference's own scene (main.cpp:526-630) -------------------------------------
+def default_scene() -> Scene:
+    """The four objects main() pushes (main.cpp:547-581): two planes, two spheres, flat colour."""
+    s = Scene()
+    s.add_plane((0, 13, 0), (0, -1, 0), (-1, 0, 0), (200, 200, 200))
+    s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+    s.add_sphere((-10.5, 0, 0), 10, (100, 200, 100))
+    s.add_sphere((10.5, 0, 0), 10, (200, 100, 100))
+    return s
+
+
+def default_lights(n=1):
+    """light_src1 of main.cpp:623 (directional) and, for n == 2, a point light at the
+    position of light_src2 (main.cpp:624)."""
+    ls = [light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 1, 1))]
+    if n >= 2:
+        ls.append(light_src(1, (30, -30, 50), (0, 0, -1), (1, 1, 1)))
+    return ls
+
+
+def default_shader(n_lights=1) -> Shader:
+    """Shader(light, Color(0x000000), Color(0xdddddd), Color(0x000000)), main.cpp:630"""
+    return Shader(default_lights(n_lights), 0x000000, 0xDDDDDD, 0x000000)
+
+
+def default_camera(width, height):
+    return camera((0, -20, 0), (0, 1, 0), (0, 0, 1), 10.0, width, height)
+
+
+# ---- synthetic: random spheres + ring of point lights -----------------------------------
+def spheres_scene(n_spheres=10000, seed=355) -> Scene:
+    """n spheres, centres uniform in [-60,60]x[10,130]x[-10,50], radii uniform [0.3,1.5],
+    colours uniform 40..255, over the floor plane z = -10."""
+    rng = SplitMix64(seed)
+    s = Scene()
+    s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+    u = rng.array(n_spheres * 7).reshape(n_spheres, 7)
+    objs = np.zeros(n_spheres, dtype=OBJECT_DTYPE)
+    objs["type"] = OBJ_SPHERE
+    objs["p"][:, 0] = -60 + 120 * u[:, 0]
+    objs["p"][:, 1] = 10 + 120 * u[:, 1]
+    objs["p"][:, 2] = -10 + 60 * u[:, 2]
+    objs["radius"] = 0.3 + 1.2 * u[:, 3]
+    objs["rgb"] = (40 + np.floor(216 * u[:, 4:7])).astype(np.uint8)
+    objs["fresnel"] = 1.0
+    objs["ior"] = 1.0
+    objs["tex0"] = objs["tex1"] = -1
+    objs["n0"] = (1, 0, 0); objs["n1"] = (0, 1, 0); objs["n2"] = (0, 0, 1)
+    s.objects.extend(list(objs))
+    return s
+
+
+def ring_lights(n=8, radius=80.0, z=80.0, center=(0.0, 70.0)):
+    """n point lights (type 1) on a ring, colour (1,1,1)."""
+    return [light_src(1, (center[0] + radius * math.cos(2 * math.pi * k / n),
+                          center[1] + radius * math.sin(2 * math.pi * k / n), z), (0, 0, -1), (1, 1, 1))
+            for k in range(n)]
+
+
+def spheres_shader(n_lights=8) -> Shader:
+    return Shader(ring_lights(n_lights), 0x101010, 0xDDDDDD, 0x000000)
+
+
+# ---- synthetic: textured height-field mesh ------------------------------------------------
+def checker_texture(size=512, cells=16, seed=356, dark=False) -> np.ndarray:
+    """Procedural checker + noise, (size,size,3) uint8."""
+    rng = SplitMix64(seed + (1 if dark else 0))
+    yy, xx = np.mgrid[0:size, 0:size]
+    chk = (((xx * cells) // size + (yy * cells) // size) & 1).astype(np.float64)
+    noise = rng.array(size * size * 3).reshape(size, size, 3)
+    base = np.where(chk[..., None] > 0, np.array([220.0, 180.0, 90.0]), np.array([60.0, 110.0, 200.0]))
+    img = base * (0.35 if dark else 1.0) + 30.0 * noise
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def heightfield_tris(nx: int, ny: int, seed=356, x0=-60.0, x1=60.0, y0=10.0, y1=130.0, zbase=-8.0,
+                     amp=6.0) -> np.ndarray:
+    """A height field z = f(x,y) over [x0,x1]x[y0,y1] as 2*nx*ny triangles wound so their
+    normals point up (+z, toward the camera and the lights), with vt in [0,1]^2."""
+    rng = SplitMix64(seed)
+    gx = np.linspace(x0, x1, nx + 1)
+    gy = np.linspace(y0, y1, ny + 1)
+    X, Y = np.meshgrid(gx, gy, indexing="xy")
+    jitter = rng.array((nx + 1) * (ny + 1)).reshape(ny + 1, nx + 1)
+    Z = (zbase + amp * (np.sin(X * 0.11) * np.cos(Y * 0.07) + 0.5 * np.sin(X * 0.31 + Y * 0.23))
+         + 0.35 * (jitter - 0.5))
+    U = (X - x0) / (x1 - x0) * 0.999
+    Vv = (Y - y0) / (y1 - y0) * 0.999
+    P = np.stack([X, Y, Z], axis=-1)
+    T = np.stack([U, Vv], axis=-1)
+    a, b = P[:-1, :-1], P[:-1, 1:]
+    c, d = P[1:, :-1], P[1:, 1:]
+    ta, tb, tc, td = T[:-1, :-1], T[:-1, 1:], T[1:, :-1], T[1:, 1:]
+    # (a,b,d) and (a,d,c): (b-a)x(d-a) has +z
+    t1 = np.concatenate([a, b, d, ta, tb, td], axis=-1).reshape(-1, 15)
+    t2 = np.concatenate([a, d, c, ta, td, tc], axis=-1).reshape(-1, 15)
+    out = np.empty((t1.shape[0] * 2, 15), dtype=np.float64)
+    out[0::2] = t1
+    out[1::2] = t2
+    return out
+
+
+def mesh_scene(n_triangles=100_000, seed=356, tex_size=512, textured=True) -> Scene:
+    """Floor plane + one textured height-field mesh of about n_triangles triangles."""
+    n = max(1, int(round(math.sqrt(n_triangles / 2.0))))
+    s = Scene()
+    s.add_plane((0, 0, -16), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+    m = s.add_mesh(heightfield_tris(n, n, seed))
+    if textured:
+        s.add_texture(m, checker_texture(tex_size, 16, seed, dark=False), 1, 1)
+        s.add_texture(m, checker_texture(tex_size, 16, seed, dark=True), 1, 1)
+        s.set_texture_type(m, 1)
+    return s
+
+
+def mesh_shader() -> Shader:
+    """Two point lights above the height field."""
+    return Shader([light_src(1, (-50, 20, 70), (0, 0, -1), (1, 1, 1)),
+                   light_src(1, (60, 90, 90), (0, 0, -1), (1, 1, 1))], 0x101010, 0xDDDDDD, 0x000000)
+
+
+def orbit_camera(frame: int, width: int, height: int, n_frames=60, center=(0.0, 70.0, 0.0), radius=90.0,
+                 eye_z=35.0):
+    """Camera `frame` of a sweep orbiting the scene centre in 360/n_frames degree steps."""
+    ang = 2 * math.pi * frame / n_frames - math.pi / 2
+    eye = (center[0] + radius * math.cos(ang), center[1] + radius * math.sin(ang), eye_z)
+    view = (center[0] - eye[0], center[1] - eye[1], center[2] - eye[2])
+    return camera(eye, view, (0, 0, 1), 10.0, width, height)
+
+
+# ---- small named cases shared by the golden-vector generator and the parity tests ---------
+def _small_texture(w, h, seed):
+    rng = SplitMix64(seed)
+    return np.floor(rng.array(w * h * 3) * 256).astype(np.uint8).reshape(h, w, 3)
+
+
+def _grid_mesh(n, seed, x0=-14.0, x1=14.0, y0=-4.0, y1=10.0, zbase=-6.0, amp=2.5):
+    return heightfield_tris(n, n, seed, x0, x1, y0, y1, zbase, amp)
+
+
+def small_case(name: str):
+    """Returns (Scene, Shader, camera, width, height) for a named parity case."""
+    if name == "default_1light":
+        w, h = 200, 150
+        return default_scene(), default_shader(1), default_camera(w, h), w, h
+    if name == "default_2lights":
+        w, h = 200, 150
+        return default_scene(), default_shader(2), default_camera(w, h), w, h
+    if name == "no_lights":
+        w, h = 64, 48
+        return default_scene(), Shader([], 0x000000, 0xDDDDDD, 0x000000), default_camera(w, h), w, h
+    if name == "empty_scene":
+        w, h = 32, 24
+        return Scene(), default_shader(1), default_camera(w, h), w, h
+    if name == "textured":
+        # textured wall + textured floor + textured sphere + flat sphere; directional, spot, point
+        w, h = 200, 150
+        s = Scene()
+        p1 = s.add_plane((0, 13, 0), (0, -1, 0), (-1, 0, 0), (200, 200, 200))
+        p2 = s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+        s1 = s.add_sphere((-10.5, 0, 0), 10, (100, 200, 100), (1, 0, 0), (0, 1, 0), (0, 0, 1))
+        s.add_sphere((10.5, 0, 2), 9, (200, 100, 100))
+        s.add_texture(p1, _small_texture(16, 8, 11), 7.0, 5.0); s.add_texture(p1, _small_texture(8, 8, 12), 7.0, 5.0)
+        s.add_texture(p2, _small_texture(12, 12, 13), 9.5, 9.5); s.add_texture(p2, _small_texture(12, 12, 14), 9.5, 9.5)
+        s.add_texture(s1, _small_texture(32, 16, 15), 1.0, 1.0); s.add_texture(s1, _small_texture(32, 16, 16), 0.5, 0.5)
+        for o in (p1, p2, s1):
+            s.set_texture_type(o, 1)
+        sh = Shader([light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 1, 1)),
+                     light_src(2, (0, -25, 30), (0, 0.6, -1), (1, 0.9, 0.8)),
+                     light_src(1, (30, -30, 50), (0, 0, -1), (0.7, 0.8, 1.0))], 0x141720, 0xDCC8FA, 0xF0F0F0)
+        return s, sh, default_camera(w, h), w, h
+    if name == "mesh":
+        # 512-triangle textured grid mesh between a floor and two spheres, two point lights
+        w, h = 160, 90
+        s = Scene()
+        s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+        s.add_sphere((-9, 12, 2), 4, (100, 200, 100))
+        m = s.add_mesh(_grid_mesh(16, 21))
+        s.add_sphere((8, 2, 3), 3, (200, 100, 100))
+        s.add_texture(m, _small_texture(16, 16, 22), 1, 1); s.add_texture(m, _small_texture(16, 16, 23), 1, 1)
+        s.set_texture_type(m, 1)
+        sh = Shader([light_src(1, (30, -30, 50), (0, 0, -1), (1, 1, 1)),
+                     light_src(1, (-25, 5, 30), (0, 0, -1), (1, 1, 1))], 0x101010, 0xDDDDDD, 0x000000)
+        return s, sh, default_camera(w, h), w, h
+    if name == "mesh_flat":
+        # untextured mesh listed BEFORE the floor, directional + point light
+        w, h = 96, 64
+        s = Scene()
+        s.add_mesh(_grid_mesh(6, 31), (150, 200, 110))
+        s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+        sh = Shader([light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 1, 1)),
+                     light_src(1, (5, -10, 40), (0, 0, -1), (1, 1, 1))], 0x000000, 0xDDDDDD, 0x000000)
+        return s, sh, default_camera(w, h), w, h
+    if name == "spheres300":
+        w, h = 160, 120
+        s = spheres_scene(300, seed=77)
+        return s, Shader(ring_lights(3), 0x101010, 0xDDDDDD, 0x202020), default_camera(w, h), w, h
+    if name == "inside":
+        # eye inside a big sphere, a light inside another, overlapping spheres, a plane behind the eye
+        w, h = 120, 90
+        s = Scene()
+        s.add_sphere((0, -18, 0), 30, (90, 120, 200))
+        s.add_sphere((-4, -5, 0), 5, (200, 100, 100))
+        s.add_sphere((1, -6, 1), 4, (100, 200, 100))
+        s.add_plane((0, -40, 0), (0, 1, 0), (-1, 0, 0), (214, 147, 44))
+        s.add_sphere((30, -30, 50), 6, (250, 250, 0))
+        sh = Shader([light_src(1, (30, -30, 50), (0, 0, -1), (1, 1, 1)),
+                     light_src(1, (2, -12, 6), (0, 0, -1), (1, 1, 1))], 0x0A0A0A, 0xDDDDDD, 0x000000)
+        return s, sh, default_camera(w, h), w, h
+    raise KeyError(name)
+
+
+SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
+               "mesh_flat", "spheres300", "inside"]
