@@ -165,6 +165,12 @@ int rt355_scene_sync(rt355_scene *scene);
  * synced render, and their count.  Used by the benchmark's roofline figure. */
 int rt355_scene_search_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *launches);
 
+/* Debug probe: objs[obj]->CalcIntersect(View(pe,npe)) for n host rays (n x 6 doubles: pe, npe)
+ * evaluated by the device's fp64 formulas; out = n x 9 doubles (t, ph[3], nh[3], uv[2]; t = -1
+ * and zeros on a miss).  Mirrors AnyObject::CalcIntersect (anyobject.h:23) one call at a time so
+ * the device arithmetic can be checked in isolation. */
+int rt355_probe_intersect(rt355_scene *scene, int obj, const double *rays, int n, double *out);
+
 const char *rt355_last_error(void);
 int rt355_abi_version(void);
 

@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference's render call on top of the C ABI (include/rt355.h).
+
+    setPixels(Scene sce, Shader shd, int alias)   -- image_synthesis/main.cpp:339-376
+
+becomes ``Renderer(scene).render(camera, shader, width, height)``.  The HIP library is the
+only backend: there is no CPU fallback, and a missing librt355.so is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .binding import ERR, MODE_FAST, CStats, COpts, PackedScene, Scene, Shader, opts as make_opts
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt355.so")
+_lib = None
+
+
+class Rt355Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Load raytracer_amd/lib/librt355.so (built by __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise Rt355Error(f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(_LIB_PATH)
+        L.rt355_last_error.restype = C.c_char_p
+        L.rt355_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt355_scene_destroy.argtypes = [C.c_void_p]
+        L.rt355_scene_destroy.restype = None
+        L.rt355_render.argtypes = [C.c_void_p] * 6
+        L.rt355_render_device.argtypes = [C.c_void_p] * 7
+        L.rt355_scene_sync.argtypes = [C.c_void_p]
+        L.rt355_scene_search_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.rt355_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise Rt355Error(f"{what}: {ERR.get(rc, rc)}: {lib().rt355_last_error().decode()}")
+
+
+class Renderer:
+    """A scene uploaded to the current HIP device (rt355_scene_create)."""
+
+    def __init__(self, scene):
+        self.packed = scene.pack() if isinstance(scene, Scene) else scene
+        assert isinstance(self.packed, PackedScene)
+        self.handle = C.c_void_p()
+        _check(lib().rt355_scene_create(C.byref(self.packed.desc), C.byref(self.handle)), "rt355_scene_create")
+        self._stats = CStats()
+
+    def close(self):
+        if self.handle:
+            lib().rt355_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam, shader: Shader, width: int, height: int, alias=0, row_begin=0, row_end=0,
+               mode=MODE_FAST, out: np.ndarray | None = None):
+        """Host framebuffer path (rt355_render).  Returns (pixmap (H,W,3) uint8, stats dict)."""
+        o = make_opts(width, height, alias, row_begin, row_end, mode)
+        if out is None:
+            out = np.zeros((height, width, 3), dtype=np.uint8)
+        st = CStats()
+        _check(lib().rt355_render(self.handle, C.byref(cam), C.byref(shader.c), C.byref(o), out.ctypes.data,
+                                  C.byref(st)), "rt355_render")
+        return out, st.as_dict()
+
+    def render_device(self, cam, shader: Shader, o: COpts, d_pixmap: int, stream: int = 0):
+        """Device framebuffer path (rt355_render_device): enqueue only; call sync() for stats."""
+        _check(lib().rt355_render_device(self.handle, C.byref(cam), C.byref(shader.c), C.byref(o),
+                                         C.c_void_p(d_pixmap), C.c_void_p(stream), C.byref(self._stats)),
+               "rt355_render_device")
+
+    def sync(self) -> dict:
+        _check(lib().rt355_scene_sync(self.handle), "rt355_scene_sync")
+        return self._stats.as_dict()
+
+    def search_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int32()
+        _check(lib().rt355_scene_search_kernel_ms(self.handle, C.byref(ms), C.byref(n)), "search_kernel_ms")
+        return ms.value, n.value
+
+    def probe_intersect(self, obj: int, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros((len(rays), 9), dtype=np.float64)
+        _check(lib().rt355_probe_intersect(self.handle, obj, rays.ctypes.data, len(rays), out.ctypes.data),
+               "rt355_probe_intersect")
+        return out

@@ -1,0 +1,854 @@
+// rt355.hip -- kernels and C ABI of the MI355X renderer (gfx950 only).
+//
+// Frame pipeline (all on one HIP stream, one launch each):
+//   k_bundle_origin   per (ray bundle, primitive): fp32 bounding cone + edge-plane tables
+//   k_gen_primary     camera rays (CalcView, main.cpp:269-276) -> fp32 directions
+//   k_search          THE HOT KERNEL: every ray of a bundle against every primitive, fp32,
+//                     conservative (no false negatives) -> per-ray candidate lists
+//   k_resolve_primary fp64 reference formulas on the candidates -> closest hit, texture
+//                     lookup, pre-shadow colour of light 0
+//   k_search          (per light: shadow rays seen from the light position)
+//   k_light_resolve   fp64 closest occluder on the candidates -> CalcShadow, running mean,
+//                     next light's pre-shadow colour or the final RGB8 store
+//
+// A "bundle" is a set of rays with a common origin: the camera rays (origin = eye) or the
+// shadow rays of one point/spot/area light traced backwards (origin = light position).  For
+// a common origin, "ray hits sphere" is "direction inside a cone" and "ray hits triangle"
+// is "direction inside a pyramid", so the all-pairs search costs 3 FMA + 1 compare per pair.
+// The search only proposes; every accepted intersection, every t and every colour comes
+// from rt_exact.h in double, so frames equal the CPU reference byte for byte.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/rt355.h"
+#include "rt_exact.h"
+
+#define RT_ABI_VERSION 1
+#define TILE_W 32           // pixels per tile edge; one workgroup searches one tile
+#define RAYS_PER_TILE 1024  // TILE_W * TILE_W
+#define SEARCH_THREADS 256
+#define RAYS_PER_THREAD 4
+#define PRIM_TILE 512       // primitives staged in LDS per step (8 KiB, double buffered)
+#define CAND_CAP 32         // candidate slots per ray; overflowing rays fall back to brute force
+#define SEARCH_MIN_PRIMS 64 // below this the fp64 brute-force walk is cheaper than a search
+
+// ---- rid <-> pixel -------------------------------------------------------------------------------
+// Rays are numbered tile-major ("rid"): rid = tile*1024 + r*256 + t, where search thread t of the
+// tile's workgroup owns rays r = 0..3.  Wave w of the workgroup covers a 16x16 pixel quarter of
+// the tile and each lane a 2x2 quad in it, so the 256 rays of a wave are neighbours on screen and
+// all per-ray buffers are read and written fully coalesced in every kernel.
+__device__ __forceinline__ void rid_to_xy(uint32_t rid, int tiles_x, int *x, int *y) {
+    uint32_t tile = rid >> 10, local = rid & 1023u;
+    uint32_t r = local >> 8, t = local & 255u, wave = t >> 6, lane = t & 63u;
+    int px = 16 * (int)(wave & 1u) + 2 * (int)(lane & 7u) + (int)(r & 1u);
+    int py = 16 * (int)(wave >> 1) + 2 * (int)(lane >> 3) + (int)(r >> 1);
+    *x = (int)(tile % (uint32_t)tiles_x) * TILE_W + px;
+    *y = (int)(tile / (uint32_t)tiles_x) * TILE_W + py;
+}
+
+struct Frame {
+    int32_t width, height, row_begin, rows; // rows of this slab
+    int32_t tiles_x, tiles_y;
+    uint32_t n_rays;                        // padded: tiles * 1024
+};
+
+struct Work { // per-ray buffers, all indexed by rid (SoA)
+    double *rec_d;      // [9][n]: ph.xyz, nh.xyz, npe.xyz of the primary hit
+    int32_t *rec_obj;   // object index of the hit, -1 miss, -2 outside the frame
+    uint32_t *rec_cm0;  // material colour | no_border << 24
+    uint32_t *rec_cm1;  // dark colour
+    uint32_t *rec_sum;  // clr_sum of Shader::shading
+    uint32_t *rec_pre;  // colour before CalcShadow | needs_shadow_ray << 24
+    float4 *ray32;      // fp32 search direction of the current bundle (NaN = inactive)
+    uint32_t *cand_cnt; // candidates found for the current bundle
+    uint32_t *cand;     // [CAND_CAP][n]
+    unsigned long long *counters; // 0 shadow rays, 1 candidates evaluated, 2 overflow rays
+};
+
+// Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
+// counter block (each on its own 128-byte line); the host adds the shards up.
+#define COUNTER_SHARDS 64
+#define COUNTER_STRIDE 16 // unsigned long longs per shard
+__device__ __forceinline__ void wave_count(unsigned long long *counters, int which, uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63u) == 0 && v)
+        atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + which], (unsigned long long)v);
+}
+
+__device__ __forceinline__ float4 nan4() {
+    float q = __builtin_nanf("");
+    return make_float4(q, q, q, q);
+}
+
+// ---- bundle tables ---------------------------------------------------------------------------------
+// L1[i] = (ox, oy, oz, -thr): unit axis and negated cosine threshold of a cone, seen from the
+// bundle origin, that contains primitive i.  A ray with unit direction d can only hit i if
+// d . o - thr >= 0.  -thr = +2 marks "always a candidate" (planes, origin inside the sphere),
+// -thr = -2 "never" (triangles facing the wrong way for the whole bundle, padding).
+// L2[3i..3i+2] = inward unit normals of the three planes through the origin and a triangle
+// edge; d can only hit the triangle if d . n >= -eps for all three.  Zero rows always pass.
+__global__ void k_bundle_origin(SceneView s, d3 O, int is_eye, int n_padded, float4 *__restrict__ L1,
+                                float4 *__restrict__ L2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_padded) return;
+    float4 never = make_float4(0.f, 0.f, 0.f, -2.f), always = make_float4(0.f, 0.f, 0.f, 2.f);
+    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 l1 = never, a = z4, b = z4, c = z4;
+    if (i < s.n_prims) {
+        int obj = s.prim_obj[i], tri = s.prim_tri[i];
+        d3 ctr; double rad; bool sphere_like = false;
+        if (tri < 0) {
+            const DObject &o = s.objects[obj];
+            if (o.type == RT_OBJ_PLANE) l1 = always;
+            else { ctr = ld3(o.p); rad = fabs(o.radius); sphere_like = true; }
+        } else {
+            const DTriangle &t = s.tris[tri];
+            d3 p0 = ld3(t.p0), p1 = ld3(t.p1), p2 = ld3(t.p2), nrm = ld3(t.normal), pc = ld3(t.p_center);
+            bool cull;
+            if (is_eye) {
+                // Triangle::CalcIntersect with pe == O: a negative plane distance gives t < 0
+                // for every direction that passes the back-face test (anyobject.h:479-501).
+                cull = dot(nrm, vsub(O, pc)) < 0;
+            } else {
+                // Shadow rays travel toward O.  A triangle whose front side faces O can only be
+                // hit beyond O, which never shadows (shader.h:413).
+                d3 w = vsub(O, pc);
+                cull = dot(nrm, w) > 1e-9 * (1.0 + vlen(w));
+            }
+            if (!cull) {
+                ctr = pc;
+                double r0 = vlen(vsub(p0, pc)), r1 = vlen(vsub(p1, pc)), r2 = vlen(vsub(p2, pc));
+                rad = fmax(r0, fmax(r1, r2));
+                sphere_like = true;
+                d3 q0 = vsub(p0, O), q1 = vsub(p1, O), q2 = vsub(p2, O);
+                d3 na = cross(q1, q2), nb = cross(q2, q0), nc = cross(q0, q1);
+                double vol = dot(na, q0);
+                double la = vlen(na), lb = vlen(nb), lc = vlen(nc);
+                double scale = vlen(q0) * vlen(q1) * vlen(q2);
+                if (fabs(vol) > 1e-7 * scale && la > 0 && lb > 0 && lc > 0) {
+                    double sg = vol > 0 ? 1.0 : -1.0;
+                    a = make_float4((float)(na.x * sg / la), (float)(na.y * sg / la), (float)(na.z * sg / la), 0.f);
+                    b = make_float4((float)(nb.x * sg / lb), (float)(nb.y * sg / lb), (float)(nb.z * sg / lb), 0.f);
+                    c = make_float4((float)(nc.x * sg / lc), (float)(nc.y * sg / lc), (float)(nc.z * sg / lc), 0.f);
+                } // else: origin (nearly) in the triangle's plane -- leave the rows zero
+            }
+        }
+        if (sphere_like) {
+            d3 oc = vsub(ctr, O);
+            double d2 = dot(oc, oc);
+            if (d2 <= rad * rad * (1.0 + 1e-5) + 1e-300) {
+                l1 = always;
+            } else {
+                double dist = sqrt(d2), sn = rad / dist;
+                double thr = sqrt(1.0 - sn * sn) - 2e-6; // fp32 evaluation error of d.o is < 4e-7
+                l1 = make_float4((float)(oc.x / dist), (float)(oc.y / dist), (float)(oc.z / dist), (float)(-thr));
+            }
+        }
+    }
+    L1[i] = l1;
+    L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
+}
+
+// ---- camera rays -------------------------------------------------------------------------------------
+__global__ void k_gen_primary(DCamera cam, Frame f, float4 *__restrict__ ray32) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rid >= f.n_rays) return;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    float4 out = nan4();
+    if (x < f.width && y < f.rows) {
+        Ray e = calc_view(cam, (double)x / (double)f.width, (double)(y + f.row_begin) / (double)f.height);
+        out = make_float4((float)e.npe.x, (float)e.npe.y, (float)e.npe.z, 0.f);
+    }
+    ray32[rid] = out;
+}
+
+// ---- the all-pairs candidate search ------------------------------------------------------------------
+// One workgroup = one 32x32 pixel tile, 4 rays per lane.  The primitive stream is staged through
+// LDS in tiles of 512 cones (double buffered, one barrier per tile); every lane reads the same
+// cone (an LDS broadcast) and tests its four directions.  The cone record holds -thr in .w, so a
+// test is three fused multiply-adds, m = d.o - thr, and the pair is a candidate iff m >= 0.
+// Primitives are taken four at a time: the sixteen m values are folded with max, and ONE compare
+// and branch per group decides whether anything in the group needs a closer look.  That branch
+// is almost never taken (a wave's 16x16 pixels see a handful of the scene's cones), and when it
+// is, the group is re-examined pair by pair, the pyramid rows of the hit triangles are fetched,
+// and survivors are appended to the rays' candidate lists in primitive order.
+#define SEARCH_GROUP 4
+
+__device__ __forceinline__ float cone_margin(float dx, float dy, float dz, const float4 &p) {
+    return __builtin_fmaf(dz, p.z, __builtin_fmaf(dy, p.y, __builtin_fmaf(dx, p.x, p.w)));
+}
+
+__device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t prim, float dx, float dy,
+                                                 float dz, uint32_t rid, uint32_t n_rays, uint32_t *cand,
+                                                 uint32_t &cnt) {
+    const float4 a = L2[3 * (size_t)prim], b = L2[3 * (size_t)prim + 1], c = L2[3 * (size_t)prim + 2];
+    float ea = __builtin_fmaf(dz, a.z, __builtin_fmaf(dy, a.y, dx * a.x));
+    float eb = __builtin_fmaf(dz, b.z, __builtin_fmaf(dy, b.y, dx * b.x));
+    float ec = __builtin_fmaf(dz, c.z, __builtin_fmaf(dy, c.y, dx * c.x));
+    if (fminf(ea, fminf(eb, ec)) >= -1e-6f) {
+        if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = prim;
+        cnt++;
+    }
+}
+
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restrict__ L1,
+                                                           const float4 *__restrict__ L2, int n_padded,
+                                                           const float4 *__restrict__ ray32, uint32_t n_rays,
+                                                           uint32_t *__restrict__ cand,
+                                                           uint32_t *__restrict__ cand_cnt) {
+    __shared__ float4 lds[2][PRIM_TILE];
+    const uint32_t t = threadIdx.x;
+    const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
+    float dx[RAYS_PER_THREAD], dy[RAYS_PER_THREAD], dz[RAYS_PER_THREAD];
+    uint32_t cnt[RAYS_PER_THREAD];
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_THREAD; r++) {
+        float4 q = ray32[base + r * SEARCH_THREADS];
+        dx[r] = q.x; dy[r] = q.y; dz[r] = q.z; cnt[r] = 0;
+    }
+    const int n_tiles = n_padded / PRIM_TILE;
+    float4 s0 = L1[t], s1 = L1[t + SEARCH_THREADS];
+    lds[0][t] = s0; lds[0][t + SEARCH_THREADS] = s1;
+    __syncthreads();
+    for (int tile = 0; tile < n_tiles; tile++) {
+        const int cur = tile & 1;
+        if (tile + 1 < n_tiles) {
+            s0 = L1[(size_t)(tile + 1) * PRIM_TILE + t];
+            s1 = L1[(size_t)(tile + 1) * PRIM_TILE + t + SEARCH_THREADS];
+        }
+        const float4 *tile_lds = lds[cur];
+        float4 nxt[SEARCH_GROUP];
+#pragma unroll
+        for (int g = 0; g < SEARCH_GROUP; g++) nxt[g] = tile_lds[g];
+#pragma unroll 2
+        for (int j = 0; j < PRIM_TILE; j += SEARCH_GROUP) {
+            float4 p[SEARCH_GROUP];
+#pragma unroll
+            for (int g = 0; g < SEARCH_GROUP; g++) p[g] = nxt[g];
+            const int jn = (j + SEARCH_GROUP) & (PRIM_TILE - 1); // the last prefetch wraps; its values are unused
+#pragma unroll
+            for (int g = 0; g < SEARCH_GROUP; g++) nxt[g] = tile_lds[jn + g];
+            float top = -3.0e38f;
+#pragma unroll
+            for (int g = 0; g < SEARCH_GROUP; g++) {
+#pragma unroll
+                for (int r = 0; r < RAYS_PER_THREAD; r++) top = fmaxf(top, cone_margin(dx[r], dy[r], dz[r], p[g]));
+            }
+            if (__builtin_expect(top >= 0.0f, 0)) {
+#pragma unroll
+                for (int g = 0; g < SEARCH_GROUP; g++) {
+                    const uint32_t prim = (uint32_t)(tile * PRIM_TILE + j + g);
+#pragma unroll
+                    for (int r = 0; r < RAYS_PER_THREAD; r++)
+                        if (cone_margin(dx[r], dy[r], dz[r], p[g]) >= 0.0f)
+                            append_candidate(L2, prim, dx[r], dy[r], dz[r], base + r * SEARCH_THREADS, n_rays, cand, cnt[r]);
+                }
+            }
+        }
+        if (tile + 1 < n_tiles) {
+            lds[cur ^ 1][t] = s0; lds[cur ^ 1][t + SEARCH_THREADS] = s1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_THREAD; r++) cand_cnt[base + r * SEARCH_THREADS] = cnt[r];
+}
+
+// ---- fp64 closest hit over a ray's candidates (or over everything) -----------------------------------
+__device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
+                                            uint32_t n_rays, const uint32_t *__restrict__ cand,
+                                            const uint32_t *__restrict__ cand_cnt, Closest &c,
+                                            uint32_t &evaluated, uint32_t &overflowed) {
+    c.init();
+    uint32_t n = 0;
+    if (!brute) {
+        n = cand_cnt[rid];
+        if (n > CAND_CAP) { brute = true; overflowed += 1; }
+    }
+    if (brute) {
+        for (int prim = 0; prim < s.n_prims; prim++) {
+            int is_mesh, obj;
+            double t = prim_t(s, prim, e, &is_mesh, &obj);
+            c.visit(prim, obj, is_mesh, t);
+        }
+        n = (uint32_t)s.n_prims;
+    } else {
+        for (uint32_t k = 0; k < n; k++) {
+            int prim = (int)cand[(size_t)k * n_rays + rid];
+            int is_mesh, obj;
+            double t = prim_t(s, prim, e, &is_mesh, &obj);
+            c.visit(prim, obj, is_mesh, t);
+        }
+    }
+    c.commit();
+    evaluated += n;
+}
+
+__device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, const Frame &f, int x, int y,
+                                            uint32_t clr) {
+    size_t i = ((size_t)(y + f.row_begin) * (size_t)f.width + (size_t)x) * 3;
+    pixmap[i] = (unsigned char)cr(clr); pixmap[i + 1] = (unsigned char)cg(clr); pixmap[i + 2] = (unsigned char)cb(clr);
+}
+
+// Colour of light k before CalcShadow (shader.h:75-89) and the shadow ray it needs.
+__device__ __forceinline__ uint32_t light_prepare(const ShaderView &sh, int k, bool searched, d3 pe, d3 ph, d3 nh,
+                                              d3 npe, uint32_t cm0, uint32_t cm1, bool no_border, uint32_t rid,
+                                              const Work &w) {
+    const DLight &L = sh.lights[k];
+    d3 nhl = light_nhl(L, ph);
+    uint32_t clr = calc_diffuse(L, cm0, cm1, nh, nhl);
+    clr = calc_specular(sh, L, clr, nh, npe, nhl);
+    if (!no_border) clr = calc_border(sh, clr, pe, ph, nh);
+    bool needs = !(dot(nh, vmul(nhl, -1)) <= 0); // shader.h:396
+    w.rec_pre[rid] = clr | (needs ? (1u << 24) : 0u);
+    if (searched) w.ray32[rid] = needs ? make_float4((float)nhl.x, (float)nhl.y, (float)nhl.z, 0.f) : nan4();
+    return needs ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+                                                         int brute, int next_searched,
+                                                         unsigned char *__restrict__ pixmap) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_shadow = 0, n_eval = 0, n_over = 0;
+    do {
+    if (rid >= f.n_rays) break;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    if (!(x < f.width && y < f.rows)) {
+        w.rec_obj[rid] = -2;
+        if (next_searched) w.ray32[rid] = nan4();
+        break;
+    }
+    Ray e = calc_view(cam, (double)x / (double)f.width, (double)(y + f.row_begin) / (double)f.height);
+    Closest c;
+    closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, c, n_eval, n_over);
+    if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
+        w.rec_obj[rid] = -1;
+        if (next_searched) w.ray32[rid] = nan4();
+        if (sh.n_lights == 0) store_pixel(pixmap, f, x, y, 0u);
+        break;
+    }
+    // the accepted hit, in full (main.cpp:69-77)
+    int obj = s.prim_obj[c.prim_best], tri = s.prim_tri[c.prim_best];
+    const DObject &o = s.objects[obj];
+    d3 ph, nh; double uvx = 0, uvy = 0;
+    if (tri >= 0) {
+        const DTriangle &T = s.tris[tri];
+        int outside; double u, v;
+        tri_t(T, e, &outside, &ph, &u, &v);
+        nh = vmul(ld3(T.normal), (double)outside);                 // anyobject.h:517
+        double wgt = 1 - u - v;                                    // Triangle::GetUV, anyobject.h:524-526
+        uvx = T.uv0[0] * wgt + T.uv1[0] * u + T.uv2[0] * v;
+        uvy = T.uv0[1] * wgt + T.uv1[1] * u + T.uv2[1] * v;
+    } else if (o.type == RT_OBJ_PLANE) {
+        d3 ni = ld3(o.n);
+        int outside = (dot(ni, vsub(e.pe, ld3(o.p))) <= 0) ? -1 : 1; // anyobject.h:71-77
+        ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :85
+        nh = vmul(ni, (double)outside);                            // :86
+    } else {
+        int outside;
+        sphere_t(o, e, &outside);
+        ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :155
+        nh = vmul(normalize(vsub(ph, ld3(o.p))), (double)outside); // :156
+    }
+    uint32_t cm0 = o.rgb, cm1 = sh.ambient;
+    if (o.texture_type == 1) texture_mapping(s, o, ph, uvx, uvy, &cm0, &cm1); // shader.h:53-58
+    bool no_border = (o.type != RT_OBJ_SPHERE);                    // main.cpp:74
+    if (sh.n_lights == 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
+        w.rec_obj[rid] = obj;
+        store_pixel(pixmap, f, x, y, 0u);
+        break;
+    }
+    const size_t n = f.n_rays;
+    w.rec_d[0 * n + rid] = ph.x; w.rec_d[1 * n + rid] = ph.y; w.rec_d[2 * n + rid] = ph.z;
+    w.rec_d[3 * n + rid] = nh.x; w.rec_d[4 * n + rid] = nh.y; w.rec_d[5 * n + rid] = nh.z;
+    w.rec_d[6 * n + rid] = e.npe.x; w.rec_d[7 * n + rid] = e.npe.y; w.rec_d[8 * n + rid] = e.npe.z;
+    w.rec_obj[rid] = obj;
+    w.rec_cm0[rid] = cm0 | (no_border ? (1u << 24) : 0u);
+    w.rec_cm1[rid] = cm1;
+    w.rec_sum[rid] = 0u;
+    n_shadow = light_prepare(sh, 0, next_searched != 0, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w);
+    } while (0);
+    wave_count(w.counters, 0, n_shadow);
+    wave_count(w.counters, 1, n_eval);
+    wave_count(w.counters, 2, n_over);
+}
+
+// CalcShadow for light k (shader.h:393-433), the running mean (shader.h:93), then either the next
+// light's pre-shadow colour or the pixel store (main.cpp:367-369).
+__global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+                                                       int k, int brute, int next_searched,
+                                                       unsigned char *__restrict__ pixmap) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_shadow = 0, n_eval = 0, n_over = 0;
+    do {
+    if (rid >= f.n_rays) break;
+    int obj = w.rec_obj[rid];
+    const bool last = (k + 1 == sh.n_lights);
+    if (obj == -2) break;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    if (obj < 0) {
+        if (last) store_pixel(pixmap, f, x, y, 0u);
+        break;
+    }
+    const size_t n = f.n_rays;
+    d3 ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
+    const DLight &L = sh.lights[k];
+    d3 nhl = light_nhl(L, ph);
+    uint32_t pre = w.rec_pre[rid];
+    double shd = 1;
+    if (pre & (1u << 24)) {
+        Ray sr = mkview(ph, vmul(nhl, -1)); // shader.h:395,404
+        Closest c;
+        closest_hit(s, sr, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, c, n_eval, n_over);
+        double Ld = vlen(vsub(ld3(L.position), ph)); // shader.h:412
+        if (c.t_best > 0 && c.t_best < Ld) shd = c.t_best / Ld;
+    } else {
+        shd = 0.5; // shader.h:396-398
+    }
+    uint32_t clr = shadow_mix(sh, L, pre & 0xffffffu, nhl, shd);
+    uint32_t sum = light_mean(w.rec_sum[rid], clr, k);
+    if (last) {
+        store_pixel(pixmap, f, x, y, sum);
+        break;
+    }
+    w.rec_sum[rid] = sum;
+    d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+    d3 npe = D3(w.rec_d[6 * n + rid], w.rec_d[7 * n + rid], w.rec_d[8 * n + rid]);
+    uint32_t cm0 = w.rec_cm0[rid];
+    n_shadow = light_prepare(sh, k + 1, next_searched != 0, ld3(cam.p_eye), ph, nh, npe, cm0 & 0xffffffu,
+                             w.rec_cm1[rid], (cm0 >> 24) & 1u, rid, w);
+    } while (0);
+    wave_count(w.counters, 0, n_shadow);
+    wave_count(w.counters, 1, n_eval);
+    wave_count(w.counters, 2, n_over);
+}
+
+// objs[obj]->CalcIntersect(View(pe,npe)) for n rays: out = t, ph[3], nh[3], uv[2] per ray.
+__global__ void k_probe_intersect(SceneView s, int obj, const double *__restrict__ rays, int n,
+                                  double *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray e = mkview(D3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), D3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]));
+    const DObject &o = s.objects[obj];
+    double t = -1, uvx = 0, uvy = 0;
+    d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
+    if (o.type == RT_OBJ_PLANE) {
+        t = plane_t(o, e);
+        if (t != -1) {
+            int outside = (dot(ld3(o.n), vsub(e.pe, ld3(o.p))) <= 0) ? -1 : 1;
+            ph = vadd(e.pe, vmul(e.npe, t)); nh = vmul(ld3(o.n), (double)outside);
+        }
+    } else if (o.type == RT_OBJ_SPHERE) {
+        int outside;
+        t = sphere_t(o, e, &outside);
+        if (t != -1) { ph = vadd(e.pe, vmul(e.npe, t)); nh = vmul(normalize(vsub(ph, ld3(o.p))), (double)outside); }
+    } else {
+        double t_min = RT_FLT_MAX; int best = -1;
+        for (int q = 0; q < o.tri_count; q++) {
+            int outside; d3 p; double u, v;
+            double tt = tri_t(s.tris[o.tri_begin + q], e, &outside, &p, &u, &v);
+            if (tt >= 0 && tt < t_min) { t_min = tt; best = q; }
+        }
+        if (t_min > 0 && t_min != RT_FLT_MAX) {
+            const DTriangle &T = s.tris[o.tri_begin + best];
+            int outside; double u, v;
+            t = tri_t(T, e, &outside, &ph, &u, &v);
+            nh = vmul(ld3(T.normal), (double)outside);
+            double wgt = 1 - u - v;
+            uvx = T.uv0[0] * wgt + T.uv1[0] * u + T.uv2[0] * v;
+            uvy = T.uv0[1] * wgt + T.uv1[1] * u + T.uv2[1] * v;
+        }
+    }
+    double *q = out + 9 * (size_t)i;
+    q[0] = t; q[1] = ph.x; q[2] = ph.y; q[3] = ph.z; q[4] = nh.x; q[5] = nh.y; q[6] = nh.z; q[7] = uvx; q[8] = uvy;
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(RT355_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+struct h3 { double x, y, z; };
+inline h3 H3(const double *p) { return {p[0], p[1], p[2]}; }
+inline h3 hsub(h3 a, h3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline h3 hadd(h3 a, h3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline h3 hmul(h3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline h3 hcross(h3 u, h3 v) { return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; }
+inline h3 hnormalize(h3 v) { // vector3D.h:79-88
+    double l = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (l != 0) return {v.x / l, v.y / l, v.z / l};
+    return v;
+}
+inline void put3(double *d, h3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+inline uint32_t pack_rgb(const uint8_t *c) { return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16); }
+} // namespace
+
+struct rt355_scene {
+    int device = 0;
+    SceneView view{};
+    int n_padded = 0;
+    bool has_tris = false;
+    // owned device allocations of the scene
+    std::vector<void *> owned;
+    // per-render bundle tables and per-ray workspace (grown on demand)
+    float4 *L1 = nullptr, *L2 = nullptr;
+    Work work{};
+    uint32_t work_rays = 0;
+    DLight *d_lights = nullptr; int lights_cap = 0;
+    // timing / stats of the outstanding render
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_search; // begin/end pairs
+    int search_launches = 0;
+    double search_ms = 0;
+    rt355_stats *pending_stats = nullptr;
+    hipStream_t pending_stream = nullptr;
+    uint64_t pending_primary = 0, pending_pairs_static = 0;
+    std::vector<int> pending_searched; // per bundle: 1 if searched
+    int pending_nprims = 0;
+    bool pending = false;
+};
+
+extern "C" const char *rt355_last_error(void) { return g_err.c_str(); }
+extern "C" int rt355_abi_version(void) { return RT_ABI_VERSION; }
+
+template <typename T>
+static int upload(rt355_scene *sc, const std::vector<T> &v, const T **out) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    sc->owned.push_back(p);
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)p;
+    return RT355_OK;
+}
+
+extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) {
+    if (!d || !out) return fail(RT355_ERR_ARG, "rt355_scene_create: null argument");
+    if (d->n_objects < 0 || d->n_triangles < 0 || d->n_textures < 0 || (d->n_objects && !d->objects) ||
+        (d->n_triangles && !d->triangles) || (d->n_textures && !d->textures))
+        return fail(RT355_ERR_ARG, "rt355_scene_create: inconsistent counts/pointers");
+    std::vector<DObject> objs(d->n_objects);
+    std::vector<DTriangle> tris(d->n_triangles);
+    std::vector<int32_t> prim_obj, prim_tri;
+    for (int i = 0; i < d->n_objects; i++) {
+        const rt355_object &o = d->objects[i];
+        if (o.type != RT355_OBJ_PLANE && o.type != RT355_OBJ_SPHERE && o.type != RT355_OBJ_MESH)
+            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": only Plane, Sphere and Mesh are accelerated");
+        if (o.ks != 0 || o.fresnel != 1)
+            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": ks != 0 or fresnel != 1 (reflection/refraction recursion, main.cpp:93-155, is not accelerated)");
+        if (o.texture_type != 0 && o.texture_type != 1)
+            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": texture_type 2/3 (solid / procedural) is not accelerated");
+        if (o.texture_type == 1 && (o.tex0 < 0 || o.tex1 < 0 || o.tex0 >= d->n_textures || o.tex1 >= d->n_textures))
+            return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": texture mapping needs textures[0] and textures[1]");
+        DObject &q = objs[i];
+        memset(&q, 0, sizeof q);
+        memcpy(q.p, o.p, sizeof q.p); memcpy(q.n, o.n, sizeof q.n);
+        memcpy(q.n0, o.n0, sizeof q.n0); memcpy(q.n1, o.n1, sizeof q.n1); memcpy(q.n2, o.n2, sizeof q.n2);
+        if (o.type == RT355_OBJ_PLANE) put3(q.n1, hcross(H3(o.n0), H3(o.n))); // Plane ctor, anyobject.h:57
+        q.radius = o.radius;
+        q.type = o.type; q.texture_type = o.texture_type; q.tex0 = o.tex0; q.tex1 = o.tex1;
+        q.tri_begin = o.tri_begin; q.tri_count = o.tri_count;
+        q.rgb = pack_rgb(o.rgb);
+        if (o.type == RT355_OBJ_MESH) {
+            if (o.tri_begin < 0 || o.tri_count < 0 || (int64_t)o.tri_begin + o.tri_count > d->n_triangles)
+                return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": triangle range out of bounds");
+            for (int k = 0; k < o.tri_count; k++) { prim_obj.push_back(i); prim_tri.push_back(o.tri_begin + k); }
+        } else {
+            prim_obj.push_back(i); prim_tri.push_back(-1);
+        }
+    }
+    for (int i = 0; i < d->n_triangles; i++) { // Triangle ctor, anyobject.h:456-461
+        const rt355_triangle &t = d->triangles[i];
+        DTriangle &q = tris[i];
+        memcpy(q.p0, t.p0, sizeof q.p0); memcpy(q.p1, t.p1, sizeof q.p1); memcpy(q.p2, t.p2, sizeof q.p2);
+        h3 p0 = H3(t.p0), p1 = H3(t.p1), p2 = H3(t.p2);
+        put3(q.normal, hnormalize(hcross(hsub(p1, p0), hsub(p2, p0))));
+        q.p_center[0] = (p0.x + p1.x + p2.x) / 3.0; q.p_center[1] = (p0.y + p1.y + p2.y) / 3.0;
+        q.p_center[2] = (p0.z + p1.z + p2.z) / 3.0;
+        memcpy(q.uv0, t.uv0, sizeof q.uv0); memcpy(q.uv1, t.uv1, sizeof q.uv1); memcpy(q.uv2, t.uv2, sizeof q.uv2);
+    }
+    std::vector<DTexture> tex(d->n_textures);
+    std::vector<uint8_t> pool;
+    for (int i = 0; i < d->n_textures; i++) {
+        const rt355_texture &t = d->textures[i];
+        if (!t.rgb || t.width <= 0 || t.height <= 0) return fail(RT355_ERR_ARG, "texture " + std::to_string(i) + ": empty");
+        tex[i].offset = pool.size(); tex[i].sx = t.sx; tex[i].sy = t.sy; tex[i].width = t.width; tex[i].height = t.height;
+        pool.insert(pool.end(), t.rgb, t.rgb + (size_t)t.width * t.height * 3);
+    }
+    rt355_scene *sc = new rt355_scene();
+    HIP_TRY(hipGetDevice(&sc->device));
+    int rc;
+    if ((rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
+        (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
+        (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels))) {
+        rt355_scene_destroy(sc);
+        return rc;
+    }
+    sc->view.n_objects = d->n_objects;
+    sc->view.n_prims = (int)prim_obj.size();
+    sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
+    if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
+    sc->has_tris = d->n_triangles > 0;
+    HIP_TRY(hipEventCreate(&sc->ev_begin));
+    HIP_TRY(hipEventCreate(&sc->ev_end));
+    void *ctr = nullptr;
+    HIP_TRY(hipMalloc(&ctr, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
+    sc->owned.push_back(ctr);
+    sc->work.counters = (unsigned long long *)ctr;
+    *out = sc;
+    return RT355_OK;
+}
+
+static void free_work(rt355_scene *sc) {
+    Work &w = sc->work;
+    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.rec_pre, w.ray32, w.cand_cnt, w.cand};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    unsigned long long *keep = w.counters;
+    w = Work{};
+    w.counters = keep;
+    sc->work_rays = 0;
+}
+
+extern "C" void rt355_scene_destroy(rt355_scene *sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    if (sc->pending && sc->pending_stream != nullptr) (void)hipStreamSynchronize(sc->pending_stream);
+    else (void)hipDeviceSynchronize();
+    free_work(sc);
+    for (void *p : sc->owned) (void)hipFree(p);
+    if (sc->L1) (void)hipFree(sc->L1);
+    if (sc->L2) (void)hipFree(sc->L2);
+    if (sc->d_lights) (void)hipFree(sc->d_lights);
+    if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
+    if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
+    for (hipEvent_t e : sc->ev_search) (void)hipEventDestroy(e);
+    delete sc;
+}
+
+static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
+    if (!sc->L1) {
+        HIP_TRY(hipMalloc((void **)&sc->L1, (size_t)sc->n_padded * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&sc->L2, (size_t)sc->n_padded * 3 * sizeof(float4)));
+    }
+    while ((int)sc->ev_search.size() < 2 * n_bundles) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        sc->ev_search.push_back(e);
+    }
+    if (n_rays <= sc->work_rays) return RT355_OK;
+    free_work(sc);
+    Work &w = sc->work;
+    size_t n = n_rays;
+    HIP_TRY(hipMalloc((void **)&w.rec_d, 9 * n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&w.rec_obj, n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&w.rec_cm0, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.rec_cm1, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.rec_sum, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.rec_pre, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.ray32, n * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&w.cand_cnt, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.cand, (size_t)CAND_CAP * n * sizeof(uint32_t)));
+    sc->work_rays = n_rays;
+    return RT355_OK;
+}
+
+static DCamera set_camera(const rt355_camera *c) { // Scene::SetCamera, main.cpp:255-262
+    DCamera o;
+    h3 v_view = H3(c->v_view), v_up = H3(c->v_up), p_eye = H3(c->p_eye);
+    h3 n_view = hnormalize(v_view);
+    h3 p_center = hadd(p_eye, hmul(n_view, c->dist));
+    h3 v0 = hcross(v_view, v_up);
+    h3 n0 = hnormalize(v0);
+    h3 n1 = hcross(n0, n_view);
+    h3 p00 = hsub(hsub(p_center, hmul(n0, c->s_x / 2)), hmul(n1, c->s_y / 2));
+    put3(o.p_eye, p_eye); put3(o.p00, p00); put3(o.n0, n0); put3(o.n1, n1);
+    o.s_x = c->s_x; o.s_y = c->s_y;
+    return o;
+}
+
+extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
+                                   const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
+    if (!sc || !cam || !shader || !opts || !d_pixmap) return fail(RT355_ERR_ARG, "rt355_render_device: null argument");
+    if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
+    if (opts->alias != 0)
+        return fail(RT355_ERR_UNSUPPORTED, "alias > 0 (jittered supersampling driven by rand(), main.cpp:286-293) is not accelerated; use alias = 0");
+    if (shader->n_lights < 0 || (shader->n_lights && !shader->lights)) return fail(RT355_ERR_ARG, "bad light list");
+    int y0 = opts->row_begin, y1 = opts->row_end;
+    if (y0 == 0 && y1 == 0) y1 = opts->height;
+    if (y0 < 0 || y1 > opts->height || y0 >= y1) return fail(RT355_ERR_ARG, "row slab out of range");
+    if (opts->mode != RT355_MODE_FAST && opts->mode != RT355_MODE_BRUTE) return fail(RT355_ERR_ARG, "unknown mode");
+    HIP_TRY(hipSetDevice(sc->device));
+    if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
+    hipStream_t st = (hipStream_t)hip_stream;
+
+    Frame f;
+    f.width = opts->width; f.height = opts->height; f.row_begin = y0; f.rows = y1 - y0;
+    f.tiles_x = (f.width + TILE_W - 1) / TILE_W; f.tiles_y = (f.rows + TILE_W - 1) / TILE_W;
+    uint64_t n_rays64 = (uint64_t)f.tiles_x * f.tiles_y * RAYS_PER_TILE;
+    if (n_rays64 > 0x7fffffffull) return fail(RT355_ERR_ARG, "slab too large: split it into fewer rows per call");
+    f.n_rays = (uint32_t)n_rays64;
+    const int nl = shader->n_lights;
+    int rc = ensure_work(sc, f.n_rays, 1 + nl);
+    if (rc) return rc;
+
+    // lights -> device
+    std::vector<DLight> hl(nl);
+    for (int i = 0; i < nl; i++) {
+        const rt355_light &l = shader->lights[i];
+        if (l.type < 0 || l.type > 3) return fail(RT355_ERR_ARG, "light type must be 0..3");
+        memcpy(hl[i].position, l.position, sizeof hl[i].position);
+        memcpy(hl[i].direction, l.direction, sizeof hl[i].direction);
+        memcpy(hl[i].color, l.color, sizeof hl[i].color);
+        hl[i].type = l.type; hl[i].pad_ = 0;
+    }
+    if (nl > sc->lights_cap) {
+        if (sc->d_lights) (void)hipFree(sc->d_lights);
+        HIP_TRY(hipMalloc((void **)&sc->d_lights, (size_t)nl * sizeof(DLight)));
+        sc->lights_cap = nl;
+    }
+    if (nl) HIP_TRY(hipMemcpyAsync(sc->d_lights, hl.data(), (size_t)nl * sizeof(DLight), hipMemcpyHostToDevice, st));
+    ShaderView sh;
+    sh.lights = sc->d_lights; sh.n_lights = nl;
+    sh.ambient = pack_rgb(shader->ambient); sh.specular = pack_rgb(shader->specular); sh.border = pack_rgb(shader->border);
+    DCamera dc = set_camera(cam);
+
+    // which bundles are searched: bundle 0 = camera rays, bundle 1+k = shadow rays of light k
+    const bool can_search = (opts->mode == RT355_MODE_FAST) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
+    std::vector<int> searched(1 + nl, 0);
+    searched[0] = can_search;
+    for (int k = 0; k < nl; k++) searched[1 + k] = can_search && hl[k].type != 0; // directional: brute for now
+
+    HIP_TRY(hipEventRecord(sc->ev_begin, st));
+    HIP_TRY(hipMemsetAsync(sc->work.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
+    const unsigned per_ray_blocks = (f.n_rays + 255) / 256;
+    const unsigned setup_blocks = (sc->n_padded + 255) / 256;
+    const unsigned n_tiles = (unsigned)(f.tiles_x * f.tiles_y);
+    unsigned char *pix = (unsigned char *)d_pixmap;
+    int launches = 0;
+    auto run_search = [&](d3 origin, int is_eye) -> int {
+        hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, origin, is_eye, sc->n_padded, sc->L1, sc->L2);
+        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
+        hipLaunchKernelGGL(k_search, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, sc->work.cand, sc->work.cand_cnt);
+        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
+        launches++;
+        return RT355_OK;
+    };
+    if (searched[0]) {
+        hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, sc->work.ray32);
+        d3 eye; eye.x = dc.p_eye[0]; eye.y = dc.p_eye[1]; eye.z = dc.p_eye[2];
+        if ((rc = run_search(eye, 1))) return rc;
+    }
+    hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work,
+                       searched[0] ? 0 : 1, nl > 0 ? searched[1] : 0, pix);
+    for (int k = 0; k < nl; k++) {
+        if (searched[1 + k]) {
+            d3 o; o.x = hl[k].position[0]; o.y = hl[k].position[1]; o.z = hl[k].position[2];
+            if ((rc = run_search(o, 0))) return rc;
+        }
+        hipLaunchKernelGGL(k_light_resolve, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work, k,
+                           searched[1 + k] ? 0 : 1, (k + 1 < nl) ? searched[2 + k] : 0, pix);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sc->ev_end, st));
+    sc->pending = true;
+    sc->pending_stats = stats;
+    sc->pending_stream = st;
+    sc->pending_primary = (uint64_t)f.width * f.rows;
+    sc->pending_searched = searched;
+    sc->pending_nprims = sc->view.n_prims;
+    sc->search_launches = launches;
+    return RT355_OK;
+}
+
+extern "C" int rt355_scene_sync(rt355_scene *sc) {
+    if (!sc) return fail(RT355_ERR_ARG, "rt355_scene_sync: null scene");
+    if (!sc->pending) return RT355_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipEventSynchronize(sc->ev_end));
+    sc->pending = false;
+    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(shards, sc->work.counters, sizeof shards, hipMemcpyDeviceToHost));
+    for (int i = 0; i < COUNTER_SHARDS; i++)
+        for (int j = 0; j < 4; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
+    sc->search_ms = 0;
+    for (int i = 0; i < sc->search_launches; i++) {
+        float m = 0;
+        HIP_TRY(hipEventElapsedTime(&m, sc->ev_search[2 * i], sc->ev_search[2 * i + 1]));
+        sc->search_ms += m;
+    }
+    if (sc->pending_stats) {
+        rt355_stats *s = sc->pending_stats;
+        s->primary_rays = sc->pending_primary;
+        s->shadow_rays = ctr[0];
+        s->exact_tests = ctr[1];
+        s->overflow_rays = ctr[2];
+        s->pair_tests = (sc->pending_primary + ctr[0]) * (uint64_t)sc->pending_nprims;
+        s->ms_device = ms;
+    }
+    return RT355_OK;
+}
+
+extern "C" int rt355_scene_search_kernel_ms(rt355_scene *sc, double *ms_sum, int32_t *launches) {
+    if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
+    *ms_sum = sc->search_ms;
+    *launches = sc->search_launches;
+    return RT355_OK;
+}
+
+extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
+                            const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats) {
+    if (!sc || !opts || !pixmap) return fail(RT355_ERR_ARG, "rt355_render: null argument");
+    if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
+    HIP_TRY(hipSetDevice(sc->device));
+    size_t bytes = (size_t)opts->width * opts->height * 3;
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    int rc = rt355_render_device(sc, cam, shader, opts, d, nullptr, stats);
+    if (rc == RT355_OK) rc = rt355_scene_sync(sc);
+    if (rc == RT355_OK) {
+        int y0 = opts->row_begin, y1 = opts->row_end;
+        if (y0 == 0 && y1 == 0) y1 = opts->height;
+        size_t off = (size_t)y0 * opts->width * 3, len = (size_t)(y1 - y0) * opts->width * 3;
+        hipError_t e = hipMemcpy(pixmap + off, (unsigned char *)d + off, len, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+// Debug probe: objs[obj]->CalcIntersect for n host rays (n x 6 doubles) -> n x 9 doubles
+// (t, ph, nh, uv).  Lets the fp64 device formulas be checked in isolation.
+extern "C" int rt355_probe_intersect(rt355_scene *sc, int obj, const double *rays, int n, double *out) {
+    if (!sc || !rays || !out || n <= 0 || obj < 0 || obj >= sc->view.n_objects) return fail(RT355_ERR_ARG, "rt355_probe_intersect: bad argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    double *dr = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **)&dr, (size_t)n * 6 * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 9 * sizeof(double)));
+    HIP_TRY(hipMemcpy(dr, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_intersect, dim3((n + 127) / 128), dim3(128), 0, 0, sc->view, obj, dr, n, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dr); (void)hipFree(dout);
+    return RT355_OK;
+}

@@ -1,0 +1,321 @@
+// rt_exact.h -- fp64 device functions that evaluate the reference's formulas operation by
+// operation (same order, same roundings; the translation unit is built with
+// -ffp-contract=off so no multiply-add is fused here).  They run only on the few
+// ray/primitive pairs that survive the fp32 candidate search, and on the one accepted hit
+// of each ray, so their cost is O(1) per ray.
+//
+// Citations are to liz425/RayTracer, image_synthesis/<file>:<line>.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_FLT_MAX 3.4028234663852886e38 /* FLT_MAX held in a double: main.cpp:45, shader.h:401 */
+#define RT_PI 3.1415927                  /* texture.h:17 (shader.h:15 and main.cpp:23 are #ifndef) */
+
+#define RT_OBJ_PLANE 0
+#define RT_OBJ_SPHERE 1
+#define RT_OBJ_MESH 2
+
+struct d3 { double x, y, z; };
+
+// ---- vector3D.h -------------------------------------------------------------------------
+__device__ __forceinline__ d3 D3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 vadd(d3 a, d3 b) { return D3(a.x + b.x, a.y + b.y, a.z + b.z); } // :33,118
+__device__ __forceinline__ d3 vsub(d3 a, d3 b) { return D3(a.x - b.x, a.y - b.y, a.z - b.z); } // :38,113
+__device__ __forceinline__ d3 vmul(d3 a, double s) { return D3(a.x * s, a.y * s, a.z * s); }   // :46
+__device__ __forceinline__ d3 vdiv(d3 a, double s) { return D3(a.x / s, a.y / s, a.z / s); }   // :42
+__device__ __forceinline__ double vlen(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); } // :50
+__device__ __forceinline__ double dot(d3 u, d3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }  // :90
+__device__ __forceinline__ d3 cross(d3 u, d3 v) {                                                // :94
+    return D3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+__device__ __forceinline__ d3 normalize(d3 v) { // :79-88
+    double l = vlen(v);
+    if (l != 0) return vdiv(v, l);
+    return v;
+}
+
+// ---- color.h ------------------------------------------------------------------------------
+// Color(char,char,char) (color.h:25) fed with a double: x86-64 converts with cvttsd2si to 32
+// bits and keeps the low byte -- toward zero, wrap mod 256, out of range or NaN -> 0.
+// v_cvt_i32_f64 saturates instead, hence the explicit range test.
+__device__ __forceinline__ uint32_t q8(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return 0u;
+    return (uint32_t)(int32_t)x & 0xffu;
+}
+// colours travel as 0x00BBGGRR in one register
+__device__ __forceinline__ uint32_t RGB(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); }
+__device__ __forceinline__ uint32_t cr(uint32_t c) { return c & 0xffu; }
+__device__ __forceinline__ uint32_t cg(uint32_t c) { return (c >> 8) & 0xffu; }
+__device__ __forceinline__ uint32_t cb(uint32_t c) { return (c >> 16) & 0xffu; }
+__device__ __forceinline__ uint32_t cmul(uint32_t c, double v) { // :33
+    return RGB(q8((double)(int)cr(c) * v), q8((double)(int)cg(c) * v), q8((double)(int)cb(c) * v));
+}
+__device__ __forceinline__ uint32_t cmulv(uint32_t c, d3 v) { // :37
+    return RGB(q8((double)(int)cr(c) * v.x), q8((double)(int)cg(c) * v.y), q8((double)(int)cb(c) * v.z));
+}
+__device__ __forceinline__ uint32_t cdivd(uint32_t c, double v) { // :41
+    return RGB(q8((double)(int)cr(c) / v), q8((double)(int)cg(c) / v), q8((double)(int)cb(c) / v));
+}
+__device__ __forceinline__ uint32_t cadd(uint32_t a, uint32_t b) { // :45, each channel wraps mod 256
+    return RGB((cr(a) + cr(b)) & 0xffu, (cg(a) + cg(b)) & 0xffu, (cb(a) + cb(b)) & 0xffu);
+}
+__device__ __forceinline__ int trunc_i32(double x) { // the reference's (int)x casts, texture.h:92-97
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int)0x80000000;
+    return (int32_t)x;
+}
+
+// ---- device scene records --------------------------------------------------------------------
+struct DObject { // one entry of Scene::objs, as uploaded
+    double p[3], n[3], n0[3], n1[3], n2[3];
+    double radius;
+    int32_t type, texture_type, tex0, tex1, tri_begin, tri_count;
+    uint32_t rgb; // 0x00BBGGRR
+    int32_t pad_;
+};
+struct DTriangle { // Triangle with its ctor-derived members (anyobject.h:456-461)
+    double p0[3], p1[3], p2[3];
+    double normal[3], p_center[3];
+    double uv0[2], uv1[2], uv2[2];
+};
+struct DTexture {
+    uint64_t offset; // byte offset into the texel pool
+    double sx, sy;
+    int32_t width, height;
+};
+struct DLight {
+    double position[3], direction[3], color[3];
+    int32_t type, pad_;
+};
+struct DCamera { // Scene::SetCamera's results (main.cpp:255-262), computed on the host in double
+    double p_eye[3], p00[3], n0[3], n1[3];
+    double s_x, s_y;
+};
+
+__device__ __forceinline__ d3 ld3(const double *p) { return D3(p[0], p[1], p[2]); }
+
+struct Ray { d3 pe, npe; };
+// View(Point3D, Vector3D) normalises its direction (view.h:23)
+__device__ __forceinline__ Ray mkview(d3 pe, d3 npe) { Ray r; r.pe = pe; r.npe = normalize(npe); return r; }
+
+// CalcView, main.cpp:269-276
+__device__ __forceinline__ Ray calc_view(const DCamera &c, double x_per, double y_per) {
+    d3 p00 = ld3(c.p00), n0 = ld3(c.n0), n1 = ld3(c.n1), pe = ld3(c.p_eye);
+    d3 pp = vadd(vadd(p00, vmul(n0, x_per * c.s_x)), vmul(n1, y_per * c.s_y));
+    d3 npe = normalize(vsub(pp, pe));
+    return mkview(pe, npe);
+}
+
+// ---- CalcIntersect: t only (enough to pick the closest hit) ----------------------------------
+// Plane::CalcIntersect, anyobject.h:69-87
+__device__ __forceinline__ double plane_t(const DObject &o, const Ray &e) {
+    d3 ni = ld3(o.n), pi = ld3(o.p);
+    if (dot(ni, e.npe) >= 0) return -1;
+    return -dot(ni, vsub(e.pe, pi)) / dot(ni, e.npe);
+}
+// Sphere::CalcIntersect, anyobject.h:128-158
+__device__ __forceinline__ double sphere_t(const DObject &o, const Ray &e, int *outside_out) {
+    d3 c = ld3(o.p);
+    double r = o.radius;
+    d3 ec = vsub(e.pe, c);
+    int outside = (dot(ec, ec) - r * r <= -0.00001) ? -1 : 1;
+    double B = dot(e.npe, vsub(c, e.pe));
+    double Cc = dot(ec, ec) - r * r;
+    double delta = B * B - Cc;
+    *outside_out = outside;
+    if (delta < 0) return -1;
+    return B - (double)outside * sqrt(delta);
+}
+// Triangle::CalcIntersect, anyobject.h:475-522
+__device__ __forceinline__ double tri_t(const DTriangle &t, const Ray &e, int *outside_out, d3 *ph_out,
+                                        double *u_out, double *v_out) {
+    d3 normal = ld3(t.normal), pc = ld3(t.p_center);
+    int outside = (dot(normal, vsub(e.pe, pc)) <= 0) ? -1 : 1;
+    *outside_out = outside;
+    if (dot(normal, e.npe) >= 0) return -1;
+    double tt = -dot(normal, vsub(e.pe, pc)) / dot(normal, e.npe);
+    if ((outside < 0 && tt > 0) || (tt < 0)) return -1;
+    d3 ph = vadd(e.pe, vmul(e.npe, tt));
+    d3 p0 = ld3(t.p0), p1 = ld3(t.p1), p2 = ld3(t.p2);
+    d3 AA = cross(vsub(p1, p0), vsub(p2, p0));
+    d3 A1 = cross(vsub(p2, ph), vsub(p0, ph));
+    d3 A2 = cross(vsub(p0, ph), vsub(p1, ph));
+    double u = (AA.x != 0) ? A1.x / AA.x : ((AA.y != 0) ? A1.y / AA.y : A1.z / AA.z);
+    double v = (AA.x != 0) ? A2.x / AA.x : ((AA.y != 0) ? A2.y / AA.y : A2.z / AA.z);
+    if (u >= 0 && v >= 0 && (u + v) <= 1) {
+        *ph_out = ph; *u_out = u; *v_out = v;
+        return tt;
+    }
+    return -1;
+}
+
+// ---- closest hit over an ordered stream of primitives -----------------------------------------
+// The scene list is walked in order and a hit is taken when `t >= 0 && t < t_min`
+// (main.cpp:68, shader.h:406), so the first object wins ties.  A Mesh first reduces its own
+// triangles the same way and reports a miss unless its minimum is > 0 (anyobject.h:646-666).
+// Primitives arrive here in scene-list order (possibly with gaps: non-candidates are misses),
+// so the per-object reduction is done on the fly and committed when the object changes.
+struct Closest {
+    double t_best; int prim_best;
+    double t_obj; int prim_obj; int cur_obj; int cur_is_mesh;
+    __device__ __forceinline__ void init() {
+        t_best = RT_FLT_MAX; prim_best = -1; t_obj = RT_FLT_MAX; prim_obj = -1; cur_obj = -1; cur_is_mesh = 0;
+    }
+    __device__ __forceinline__ void commit() {
+        if (cur_obj < 0) return;
+        double tt = t_obj;
+        if (cur_is_mesh) { if (!(t_obj > 0 && t_obj != RT_FLT_MAX)) tt = -1; }
+        else if (t_obj == RT_FLT_MAX) tt = -1;
+        if (tt >= 0 && tt < t_best) { t_best = tt; prim_best = prim_obj; }
+        cur_obj = -1;
+    }
+    __device__ __forceinline__ void visit(int prim, int obj, int is_mesh, double t) {
+        if (obj != cur_obj) { commit(); cur_obj = obj; cur_is_mesh = is_mesh; t_obj = RT_FLT_MAX; prim_obj = -1; }
+        if (t >= 0 && t < t_obj) { t_obj = t; prim_obj = prim; }
+    }
+};
+
+struct SceneView { // device pointers of an uploaded scene
+    const DObject *objects;
+    const DTriangle *tris;
+    const int32_t *prim_obj;   // primitive -> object index
+    const int32_t *prim_tri;   // primitive -> triangle index, or -1 for a plane / sphere
+    const DTexture *textures;
+    const uint8_t *texels;
+    int32_t n_objects, n_prims;
+};
+
+__device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray &e, int *is_mesh, int *obj_out) {
+    int obj = s.prim_obj[prim];
+    int tri = s.prim_tri[prim];
+    *obj_out = obj;
+    if (tri >= 0) {
+        int outside; d3 ph; double u, v;
+        *is_mesh = 1;
+        return tri_t(s.tris[tri], e, &outside, &ph, &u, &v);
+    }
+    *is_mesh = 0;
+    const DObject &o = s.objects[obj];
+    if (o.type == RT_OBJ_PLANE) return plane_t(o, e);
+    int outside;
+    return sphere_t(o, e, &outside);
+}
+
+// ---- texture.h ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t texel(const uint8_t *px, int idx) {
+    return RGB(px[3 * idx], px[3 * idx + 1], px[3 * idx + 2]);
+}
+// common tail of GetColorSphere / GetColorPlane, texture.h:92-103 / 110-121: each term is
+// truncated twice, the three additions wrap.
+__device__ __forceinline__ uint32_t bilinear(const DTexture &t, const uint8_t *pool, double x, double y) {
+    const uint8_t *px = pool + t.offset;
+    int ix = trunc_i32(x), iy = trunc_i32(y);
+    double u = x - (double)ix, v = y - (double)iy;
+    int W = t.width, H = t.height;
+    int pre00 = iy % H * W + ix % W;
+    int pre01 = (iy + 1) % H * W + ix % W;
+    int pre11 = (iy + 1) % H * W + (ix + 1) % W;
+    int pre10 = iy % H * W + (ix + 1) % W;
+    uint32_t a = cmul(cmul(texel(px, pre00), 1 - u), 1 - v);
+    uint32_t b = cmul(cmul(texel(px, pre01), 1 - u), v);
+    uint32_t c = cmul(cmul(texel(px, pre11), u), v);
+    uint32_t d = cmul(cmul(texel(px, pre10), u), 1 - v);
+    return cadd(cadd(cadd(a, b), c), d);
+}
+__device__ __forceinline__ uint32_t tex_sphere(const DTexture &t, const uint8_t *pool, double theta, double phi) {
+    double x = theta / (2 * RT_PI) * (double)t.width / t.sx; // texture.h:82
+    double y = phi / RT_PI * (double)t.height / t.sy;        // texture.h:83
+    return bilinear(t, pool, x, y);
+}
+__device__ __forceinline__ uint32_t tex_plane(const DTexture &t, const uint8_t *pool, double x, double y) {
+    return bilinear(t, pool, x * (double)t.width, y * (double)t.height); // texture.h:108-109
+}
+
+// Shader::TextureMapping, shader.h:196-288 (normal map off, shader.h:23)
+__device__ __forceinline__ void texture_mapping(const SceneView &s, const DObject &o, d3 ph, double uvx,
+                                                double uvy, uint32_t *cm0, uint32_t *cm1) {
+    const DTexture &t0 = s.textures[o.tex0];
+    const DTexture &t1 = s.textures[o.tex1];
+    if (o.type == RT_OBJ_SPHERE) {
+        d3 c = ld3(o.p);
+        double x = dot(ld3(o.n0), vsub(ph, c)) / o.radius;
+        double y = dot(ld3(o.n1), vsub(ph, c)) / o.radius;
+        double z = dot(ld3(o.n2), vsub(ph, c)) / o.radius;
+        double phi = RT_PI - acos(z);
+        double theta = 0;
+        if (z != 1 && z != -1) {
+            double sss = y / sqrt(1 - z * z);
+            if (sss > -1 && sss < 1) theta = acos(sss);
+            else if (sss == 1) theta = 0;
+            else if (sss == -1) theta = RT_PI;
+            else theta = 0;
+        }
+        if (x < 0) theta = 2 * RT_PI - theta;
+        *cm0 = tex_sphere(t0, s.texels, theta, phi);
+        *cm1 = tex_sphere(t1, s.texels, theta, phi);
+    } else if (o.type == RT_OBJ_PLANE) {
+        d3 pi = ld3(o.p);
+        double x = dot(ld3(o.n0), vsub(ph, pi)) / t0.sx;
+        x = x - (double)trunc_i32(x);
+        double y = dot(ld3(o.n1), vsub(ph, pi)) / t0.sy;
+        y = y - (double)trunc_i32(y);
+        x = (x < 0) ? x + 1 : x;
+        y = (y < 0) ? y + 1 : y;
+        *cm0 = tex_plane(t0, s.texels, x, y);
+        *cm1 = tex_plane(t1, s.texels, x, y);
+    } else {
+        *cm0 = tex_plane(t0, s.texels, uvx, uvy);
+        *cm1 = tex_plane(t1, s.texels, uvx, uvy);
+    }
+}
+
+// ---- shader.h -------------------------------------------------------------------------------------
+struct ShaderView {
+    const DLight *lights;
+    int32_t n_lights;
+    uint32_t ambient, specular, border; // 0x00BBGGRR
+};
+
+// nhl of Shader::shading, shader.h:75-82
+__device__ __forceinline__ d3 light_nhl(const DLight &L, d3 ph) {
+    if (L.type == 0) return ld3(L.direction);
+    return normalize(vsub(ph, ld3(L.position)));
+}
+__device__ __forceinline__ double spot_factor(const DLight &L, d3 nhl) { // pow(x,1), shader.h:332,370,426
+    return (dot(ld3(L.direction), nhl) + 1) / 2.0;
+}
+// CalcDiffuse, shader.h:324-338
+__device__ __forceinline__ uint32_t calc_diffuse(const DLight &L, uint32_t cm0, uint32_t cm1, d3 nh, d3 nhl) {
+    double t = (dot(nh, vmul(nhl, -1)) + 1) / 2.0;
+    if (L.type == 2) t = t * spot_factor(L, nhl);
+    d3 lc = vmul(ld3(L.color), t);
+    return cadd(cmulv(cm0, lc), cmulv(cm1, vsub(D3(1, 1, 1), lc)));
+}
+// CalcSpecular, shader.h:340-376 (SpecularType 0)
+__device__ __forceinline__ uint32_t calc_specular(const ShaderView &sh, const DLight &L, uint32_t clr, d3 nh,
+                                                  d3 npe, d3 nhl) {
+    d3 reh = normalize(vsub(npe, vmul(nh, 2 * dot(nh, npe))));
+    double s = dot(vmul(nhl, -1), reh);
+    s = (s > 0) ? s : 0;
+    s = pow(s, 25.0);
+    if (L.type == 2) s = s * spot_factor(L, nhl);
+    return cadd(cmul(clr, 1 - s), cmul(sh.specular, s));
+}
+// CalcBorder, shader.h:378-387
+__device__ __forceinline__ uint32_t calc_border(const ShaderView &sh, uint32_t clr, d3 pe, d3 ph, d3 nh) {
+    double b = 1 - dot(normalize(vsub(pe, ph)), nh);
+    double mn = 0.8, mx = 0.9;
+    b = (b - mn) / (mx - mn);
+    b = (b > 1) ? 1 : ((b < 0) ? 0 : b);
+    return cadd(cmul(clr, 1 - b), cmul(sh.border, b));
+}
+// tail of CalcShadow, shader.h:412-432, given the closest occluder distance
+__device__ __forceinline__ uint32_t shadow_mix(const ShaderView &sh, const DLight &L, uint32_t clr, d3 nhl,
+                                               double shd) {
+    if (L.type == 2) shd = shd * spot_factor(L, nhl);
+    return cadd(cmul(clr, shd), cmul(sh.ambient, 1 - shd));
+}
+// running mean over lights, shader.h:93
+__device__ __forceinline__ uint32_t light_mean(uint32_t clr_sum, uint32_t clr, int k) {
+    return cadd(cmul(cdivd(clr_sum, (double)k + 1.0), (double)k), cdivd(clr, (double)k + 1.0));
+}

@@ -1,0 +1,35 @@
+"""CPU: the C-ABI library loads and exports every symbol include/rt355.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    names = set(re.findall(r"\b(rt355_[a-z_0-9]+)\s*\(", hdr))
+    assert {"rt355_scene_create", "rt355_render", "rt355_render_device", "rt355_scene_destroy"} <= names
+    so = os.path.join(ROOT, "raytracer_amd", "lib", "librt355.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    L = ctypes.CDLL(so)
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in rt355.h but not exported"
+    L.rt355_abi_version.restype = ctypes.c_int
+    assert L.rt355_abi_version() >= 1
+
+
+def test_struct_sizes_match_header_layout():
+    from raytracer_amd import binding as B
+    assert B.OBJECT_DTYPE.itemsize == 184 and B.LIGHT_DTYPE.itemsize == 80
+    assert ctypes.sizeof(B.CCamera) == 96 and ctypes.sizeof(B.CStats) == 48
+
+
+def test_null_arguments_are_rejected_without_a_gpu():
+    from raytracer_amd import api
+    L = api.lib()
+    out = ctypes.c_void_p()
+    assert L.rt355_scene_create(None, ctypes.byref(out)) == -1
+    assert b"null" in L.rt355_last_error()
