@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Benchmark of the accelerated render path: Mrays/s (primary + shadow) at 3840x2160.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shard frames|slabs]
+
+One step = one frame of the workload rendered by rt355_render_device into a framebuffer that
+stays in HBM (scene, tables and framebuffer are all device-resident when the timed region
+starts).  N > 1 is launched by torch.distributed.run, one rank per GPU; ranks render whole
+frames independently (weak scaling, no data-path collective) or, with --shard slabs, row slabs
+of one frame followed by the final-frame gather over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (= the f32-input MFMA peak), datasheet
+# flops per ray/primitive test of the REFERENCE formulas (common sub-expressions shared):
+ALGO_FLOPS = {"sphere": 18.0, "plane": 14.0, "tri_front": 50.0, "tri_culled": 13.0}
+# flops the search kernel EXECUTES per pair: 3 FMA (6) + its share of the max-fold (8 max3 per
+# 16 pairs, 2 compares each = 1) + 1/16 of the group compare
+EXEC_FLOPS_PER_PAIR = 6.0 + 1.0 + 1.0 / 16.0
+
+
+def build_workload(name: str):
+    from raytracer_amd import scenes as S
+    if name == "spheres10k_8lights_4k":
+        w, h = 3840, 2160
+        return S.spheres_scene(10000, seed=355), S.spheres_shader(8), S.default_camera(w, h), w, h
+    if name == "default_4k":
+        w, h = 3840, 2160
+        return S.default_scene(), S.default_shader(1), S.default_camera(w, h), w, h
+    if name == "mesh100k_2lights_4k":
+        w, h = 3840, 2160
+        return S.mesh_scene(100_000, seed=356), S.mesh_shader(), S.default_camera(w, h), w, h
+    if name == "mesh1m_2lights_8k":
+        w, h = 7680, 4320
+        return S.mesh_scene(1_000_000, seed=356), S.mesh_shader(), S.default_camera(w, h), w, h
+    if name == "spheres1k_2lights_small":  # quick functional run
+        w, h = 640, 360
+        return S.spheres_scene(1000, seed=355), S.spheres_shader(2), S.default_camera(w, h), w, h
+    raise SystemExit(f"unknown workload {name}")
+
+
+def algorithmic_flops(scene, shader, cam, stats) -> float:
+    """Reference-formula flops of one frame: sum over rays and primitives of the per-test figure.
+    A triangle test counts 50 when the bundle origin lies on the triangle's front side (so rays can
+    pass the back-face test), else 13."""
+    from raytracer_amd import binding as B
+    objs = scene.pack().objects
+    n_pl = int((objs["type"] == B.OBJ_PLANE).sum())
+    n_sp = int((objs["type"] == B.OBJ_SPHERE).sum())
+    base = n_pl * ALGO_FLOPS["plane"] + n_sp * ALGO_FLOPS["sphere"]
+    tris = np.concatenate(scene.triangles, axis=0) if scene.triangles else np.zeros((0, 15))
+    n_lights = len(shader.lights)
+    per_ray_primary = base
+    per_ray_shadow = [base] * n_lights
+    if len(tris):
+        p0, p1, p2 = tris[:, 0:3], tris[:, 3:6], tris[:, 6:9]
+        nrm = np.cross(p1 - p0, p2 - p0)
+        pc = (p0 + p1 + p2) / 3.0
+        eye = np.array(list(cam.p_eye))
+        front = ((nrm * (eye - pc)).sum(axis=1) > 0).sum()
+        per_ray_primary += front * ALGO_FLOPS["tri_front"] + (len(tris) - front) * ALGO_FLOPS["tri_culled"]
+        for k in range(n_lights):
+            # a shadow ray can only pass the back-face test of triangles whose BACK faces the light
+            lp = shader.lights[k]["position"]
+            back = ((nrm * (lp - pc)).sum(axis=1) < 0).sum()
+            per_ray_shadow[k] += back * ALGO_FLOPS["tri_front"] + (len(tris) - back) * ALGO_FLOPS["tri_culled"]
+    shadow_per_light = stats["shadow_rays"] / max(1, n_lights)
+    return stats["primary_rays"] * per_ray_primary + sum(shadow_per_light * f for f in per_ray_shadow)
+
+
+def cpu_baseline(scene, shader, cam, w, h, stride, threads):
+    """The CPU checker (oracle/rt_oracle.c, a port of the reference path) timed on a strided
+    pixel sample of the same frame."""
+    from oracle.oracle_py import Oracle
+    from raytracer_amd import binding as B
+    O = Oracle()
+    p = scene.pack()
+    t0 = time.perf_counter()
+    _, st = O.render(p, cam, shader, B.opts(w, h), threads=threads, stride=stride)
+    dt = time.perf_counter() - t0
+    rays = st["primary_rays"] + st["shadow_rays"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
+                      f"{st['shadow_rays']} shadow rays, {dt:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="spheres10k_8lights_4k")
+    ap.add_argument("--shard", choices=["frames", "slabs"], default="frames")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracer_amd import binding as B
+    from raytracer_amd.api import Renderer
+
+    scene, shader, cam, w, h = build_workload(args.workload)
+    r = Renderer(scene)
+    fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    if args.shard == "slabs" and world > 1:
+        rows = [(h * i) // world for i in range(world + 1)]
+        o = B.opts(w, h, row_begin=rows[rank], row_end=rows[rank + 1])
+        gather_list = None
+        slab_rows = max(rows[i + 1] - rows[i] for i in range(world))
+        send = torch.zeros((slab_rows, w, 3), dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            gather_list = [torch.zeros_like(send) for _ in range(world)]
+    else:
+        o = B.opts(w, h)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        r.render_device(cam, shader, o, fb.data_ptr(), stream)
+        if args.shard == "slabs" and world > 1:
+            # the only exchange of the path: the final frame is gathered on rank 0
+            n = o.row_end - o.row_begin
+            send[:n].copy_(fb[o.row_begin:o.row_end])
+            dist.gather(send, gather_list, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    search_ms, search_launches, pairs_total = 0.0, 0, 0
+    t0 = time.perf_counter()
+    stats = None
+    for _ in range(args.steps):
+        step()
+        stats = r.sync()  # waits for this frame's events (frames are serial on the stream anyway)
+        ms, n = r.search_kernel_ms()
+        search_ms += ms
+        search_launches += n
+        pairs_total += stats["pair_tests"] if n else 0
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        rays_local = torch.tensor([float(stats["primary_rays"] + stats["shadow_rays"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rays_local, op=dist.ReduceOp.SUM)
+        rays_step = float(rays_local.item())
+    else:
+        rays_step = float(stats["primary_rays"] + stats["shadow_rays"])
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        value = rays_step * args.steps / dt / 1e6
+        out = {
+            "metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak" if (args.shard == "frames" or world == 1) else "strong",
+            "vs_baseline": None, "dtype": "f32 search + f64 resolve", "data": "synthetic",
+            "config": {"workload": args.workload, "width": w, "height": h, "primitives": scene.n_primitives,
+                       "lights": len(shader.lights), "alias": 0, "shard": args.shard,
+                       "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"]},
+                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"]},
+        }
+        if search_launches:
+            avg_ms = search_ms / search_launches
+            pairs_per_launch = pairs_total / search_launches
+            exec_tflops = pairs_per_launch * EXEC_FLOPS_PER_PAIR / (avg_ms * 1e-3) / 1e12
+            algo = algorithmic_flops(scene, shader, cam, stats) * args.steps / search_launches
+            algo_tflops = algo / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "valu_fp32", "kernel": "k_search", "achieved": round(exec_tflops, 2), "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(exec_tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                "launches_per_frame": search_launches // args.steps, "avg_launch_ms": round(avg_ms, 4),
+                "pairs_per_launch": pairs_per_launch, "flops_per_pair_executed": EXEC_FLOPS_PER_PAIR,
+                "search_share_of_frame": round(search_ms / (dt * 1e3), 4),
+                "reference_formula_equivalent": {"tflops": round(algo_tflops, 2),
+                                                 "frac_of_peak": round(algo_tflops / PEAK_FP32_TFLOPS, 4),
+                                                 "flops_per_test": ALGO_FLOPS},
+            }
+        else:
+            out["roofline"] = None
+        if not args.no_cpu_baseline and world == 1:
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            stride = args.cpu_stride
+            if stride == 0:
+                work = scene.n_primitives * (1 + len(shader.lights))
+                stride = 1 if work < 200 else (4 if work < 5000 else 16)
+            out["cpu_baseline"] = cpu_baseline(scene, shader, cam, w, h, stride, threads)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

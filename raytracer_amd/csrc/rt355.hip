@@ -70,6 +70,8 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *cand_cnt; // candidates found for the current bundle
     uint32_t *cand;     // [CAND_CAP][n]
     unsigned long long *counters; // 0 shadow rays, 1 candidates evaluated, 2 overflow rays
+    uint32_t *tile_count; // [tiles + 1] active rays per tile, then exclusive offsets; last = total
+    uint32_t *active_rid; // [n] rids of the current bundle's active rays, tile-major order kept
 };
 
 // Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
@@ -171,6 +173,79 @@ __global__ void k_gen_primary(DCamera cam, Frame f, float4 *__restrict__ ray32) 
     ray32[rid] = out;
 }
 
+// ---- compaction of a bundle's active rays -------------------------------------------------------------
+// Shadow rays exist only for hits that face the light, so a bundle's active rays can be a small
+// part of the frame (sky pixels, back-facing hits).  Three small kernels keep the search dense:
+// count the active rays of each tile, scan the counts, scatter the active rids in tile-major
+// order.  The search then runs over the compacted list; results stay indexed by rid.
+__device__ __forceinline__ bool ray_active(const float4 *__restrict__ ray32, uint32_t rid) {
+    float x = ray32[rid].x;
+    return x == x; // inactive rays hold NaN
+}
+
+__global__ __launch_bounds__(SEARCH_THREADS) void k_count_active(const float4 *__restrict__ ray32,
+                                                                  uint32_t *__restrict__ tile_count) {
+    __shared__ uint32_t wsum[SEARCH_THREADS / 64];
+    const uint32_t t = threadIdx.x, base = blockIdx.x * RAYS_PER_TILE + t;
+    uint32_t n = 0;
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_THREAD; r++) n += ray_active(ray32, base + r * SEARCH_THREADS) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((t & 63u) == 0) wsum[t >> 6] = n;
+    __syncthreads();
+    if (t == 0) tile_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of n_tiles counts in place (single workgroup); tile_count[n_tiles] = total
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *__restrict__ tile_count, int n_tiles) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n_tiles + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, n_tiles);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += tile_count[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t v = (t >= off) ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int i = lo; i < hi; i++) { uint32_t c = tile_count[i]; tile_count[i] = run; run += c; }
+    if (t == 1023) tile_count[n_tiles] = part[1023];
+}
+
+__global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 *__restrict__ ray32,
+                                                                    const uint32_t *__restrict__ tile_count,
+                                                                    uint32_t *__restrict__ active_rid) {
+    __shared__ uint32_t wsum[RAYS_PER_THREAD][SEARCH_THREADS / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
+    bool act[RAYS_PER_THREAD];
+    uint32_t below[RAYS_PER_THREAD];
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_THREAD; r++) {
+        act[r] = ray_active(ray32, base + r * SEARCH_THREADS);
+        unsigned long long m = __ballot(act[r]);
+        below[r] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[r][wave] = __popcll(m);
+    }
+    __syncthreads();
+    // rank of local index r*256 + t among the tile's active rays
+    uint32_t run = tile_count[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_THREAD; r++) {
+#pragma unroll
+        for (int w = 0; w < SEARCH_THREADS / 64; w++) {
+            if ((uint32_t)w == wave && act[r]) active_rid[run + below[r]] = base + r * SEARCH_THREADS;
+            run += wsum[r][w];
+        }
+    }
+}
+
 // ---- the all-pairs candidate search ------------------------------------------------------------------
 // One workgroup = one 32x32 pixel tile, 4 rays per lane.  The primitive stream is staged through
 // LDS in tiles of 512 cones (double buffered, one barrier per tile); every lane reads the same
@@ -203,16 +278,25 @@ __device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, 
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restrict__ L1,
                                                            const float4 *__restrict__ L2, int n_padded,
                                                            const float4 *__restrict__ ray32, uint32_t n_rays,
+                                                           const uint32_t *__restrict__ active_rid,
+                                                           const uint32_t *__restrict__ n_active,
                                                            uint32_t *__restrict__ cand,
                                                            uint32_t *__restrict__ cand_cnt) {
     __shared__ float4 lds[2][PRIM_TILE];
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
+    // active_rid == nullptr: the bundle is the whole frame, ray = rid.  Otherwise workgroup b
+    // takes entries [1024 b, 1024 b + 1024) of the compacted list and retires if there are none.
+    const uint32_t total = active_rid ? *n_active : n_rays;
+    if (blockIdx.x * RAYS_PER_TILE >= total) return;
     float dx[RAYS_PER_THREAD], dy[RAYS_PER_THREAD], dz[RAYS_PER_THREAD];
-    uint32_t cnt[RAYS_PER_THREAD];
+    uint32_t cnt[RAYS_PER_THREAD], rid[RAYS_PER_THREAD];
 #pragma unroll
     for (int r = 0; r < RAYS_PER_THREAD; r++) {
-        float4 q = ray32[base + r * SEARCH_THREADS];
+        const uint32_t slot = base + r * SEARCH_THREADS;
+        const bool live = slot < total;
+        rid[r] = active_rid ? (live ? active_rid[slot] : 0u) : slot;
+        float4 q = live ? ray32[rid[r]] : nan4();
         dx[r] = q.x; dy[r] = q.y; dz[r] = q.z; cnt[r] = 0;
     }
     const int n_tiles = n_padded / PRIM_TILE;
@@ -250,7 +334,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
 #pragma unroll
                     for (int r = 0; r < RAYS_PER_THREAD; r++)
                         if (cone_margin(dx[r], dy[r], dz[r], p[g]) >= 0.0f)
-                            append_candidate(L2, prim, dx[r], dy[r], dz[r], base + r * SEARCH_THREADS, n_rays, cand, cnt[r]);
+                            append_candidate(L2, prim, dx[r], dy[r], dz[r], rid[r], n_rays, cand, cnt[r]);
                 }
             }
         }
@@ -260,7 +344,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
         __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < RAYS_PER_THREAD; r++) cand_cnt[base + r * SEARCH_THREADS] = cnt[r];
+    for (int r = 0; r < RAYS_PER_THREAD; r++)
+        if (base + r * SEARCH_THREADS < total) cand_cnt[rid[r]] = cnt[r];
 }
 
 // ---- fp64 closest hit over a ray's candidates (or over everything) -----------------------------------
@@ -620,7 +705,8 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
-    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.rec_pre, w.ray32, w.cand_cnt, w.cand};
+    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.rec_pre, w.ray32, w.cand_cnt, w.cand,
+                  w.tile_count, w.active_rid};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
     w = Work{};
@@ -667,6 +753,8 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
     HIP_TRY(hipMalloc((void **)&w.ray32, n * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, (size_t)CAND_CAP * n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.tile_count, (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.active_rid, n * sizeof(uint32_t)));
     sc->work_rays = n_rays;
     return RT355_OK;
 }
@@ -746,8 +834,15 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     int launches = 0;
     auto run_search = [&](d3 origin, int is_eye) -> int {
         hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, origin, is_eye, sc->n_padded, sc->L1, sc->L2);
+        const uint32_t *list = nullptr, *total = nullptr;
+        if (!is_eye) { // shadow bundles are sparse: compact their active rays first
+            hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, sc->work.tile_count, (int)n_tiles);
+            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count, sc->work.active_rid);
+            list = sc->work.active_rid; total = sc->work.tile_count + n_tiles;
+        }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
-        hipLaunchKernelGGL(k_search, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, sc->work.cand, sc->work.cand_cnt);
+        hipLaunchKernelGGL(k_search, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
         launches++;
         return RT355_OK;
