@@ -131,14 +131,10 @@ def main():
     scene, shader, cam, w, h = build_workload(args.workload)
     r = Renderer(scene)
     fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    from raytracer_amd.sharding import gather_frame, slab_rows
     if args.shard == "slabs" and world > 1:
-        rows = [(h * i) // world for i in range(world + 1)]
-        o = B.opts(w, h, row_begin=rows[rank], row_end=rows[rank + 1])
-        gather_list = None
-        slab_rows = max(rows[i + 1] - rows[i] for i in range(world))
-        send = torch.zeros((slab_rows, w, 3), dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            gather_list = [torch.zeros_like(send) for _ in range(world)]
+        b, e = slab_rows(h, world)[rank]
+        o = B.opts(w, h, row_begin=b, row_end=e)
     else:
         o = B.opts(w, h)
     stream = torch.cuda.current_stream().cuda_stream
@@ -146,10 +142,7 @@ def main():
     def step():
         r.render_device(cam, shader, o, fb.data_ptr(), stream)
         if args.shard == "slabs" and world > 1:
-            # the only exchange of the path: the final frame is gathered on rank 0
-            n = o.row_end - o.row_begin
-            send[:n].copy_(fb[o.row_begin:o.row_end])
-            dist.gather(send, gather_list, dst=0)
+            gather_frame(fb, rank, world, dst=0)  # the only exchange of the path: the final frame
 
     def barrier():
         if world > 1:

@@ -94,6 +94,8 @@ class Reference:
                                    C.c_void_p]
         L.ref_texture.restype = C.c_int
         L.ref_texture.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p]
+        L.ref_adaptor_roundtrip.restype = C.c_int
+        L.ref_adaptor_roundtrip.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         self.L = L
         self.tmp = tempfile.mkdtemp(prefix="rt355_ref_")
 
@@ -108,6 +110,9 @@ class Reference:
         if rc != 0:
             raise RuntimeError(f"ref_render failed: {rc}")
         return out
+
+    def adaptor_roundtrip(self, packed, shader) -> int:
+        return int(self.L.ref_adaptor_roundtrip(C.byref(packed.desc), C.byref(shader.c), self.tmp.encode()))
 
     def intersect_many(self, packed, obj: int, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

@@ -12,7 +12,7 @@
 // on the path (Scene::SetCamera 255-262, CalcView 269-276, the closest-hit loop of
 // CalcSubPixel 42-91, the alias==0 branch of CalcPixel 326-332 and setPixels 355-370)
 // are therefore re-expressed below with the reference's own vector/colour types.  That
-// part is pinned by the frame hashes BASELINE.md records from a run of main.cpp itself.
+// part is pinned by the 18 pixel values BASELINE.md records from a run of main.cpp itself.
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -32,6 +32,7 @@
 #include "anyobject.h"
 
 #include "../include/rt355.h"
+#include "../include/rt355_reference_adaptor.hpp"
 
 namespace {
 
@@ -272,6 +273,58 @@ int ref_texture(const rt355_texture *t, int kind, const double *ab, int n, unsig
         out[3 * i] = r.r; out[3 * i + 1] = r.g; out[3 * i + 2] = r.b;
     }
     return 0;
+}
+
+// Build reference objects from a descriptor, run the maintainer-side adaptor
+// (include/rt355_reference_adaptor.hpp) over them and compare what it produces with the
+// descriptor we started from.  Returns 0 when identical, else a positive code.
+int ref_adaptor_roundtrip(const rt355_scene_desc *d, const rt355_shader *sh, const char *tmpdir) {
+    RefScene rs;
+    if (!build(d, tmpdir, rs)) return -1;
+    // Texture::pixmap is private: hand the adaptor the bytes the BMPs were written from
+    std::vector<const Texture *> order;
+    std::vector<const unsigned char *> bytes;
+    for (size_t i = 0; i < rs.objs.size(); i++) {
+        const rt355_object &o = d->objects[i];
+        int ids[2] = {o.tex0, o.tex1};
+        for (size_t k = 0; k < rs.objs[i]->textures.size(); k++) {
+            order.push_back(rs.objs[i]->textures[k]);
+            bytes.push_back(d->textures[ids[k]].rgb);
+        }
+    }
+    auto texels = [&](const Texture *t) -> const unsigned char * {
+        for (size_t i = 0; i < order.size(); i++) if (order[i] == t) return bytes[i];
+        return nullptr;
+    };
+    Rt355Flattened f = rt355_flatten(rs.objs, texels);
+    if ((int)f.objects.size() != d->n_objects) return 1;
+    if ((int)f.triangles.size() != d->n_triangles) return 2;
+    for (int i = 0; i < d->n_objects; i++) {
+        const rt355_object &a = d->objects[i], &b = f.objects[i];
+        if (a.type != b.type || a.texture_type != b.texture_type || memcmp(a.rgb, b.rgb, 3)) return 10 + i;
+        if (a.ks != b.ks || a.fresnel != b.fresnel || a.ior != b.ior) return 10 + i;
+        if (a.type == RT355_OBJ_PLANE && (memcmp(a.p, b.p, 24) || memcmp(a.n, b.n, 24) || memcmp(a.n0, b.n0, 24))) return 10 + i;
+        if (a.type == RT355_OBJ_SPHERE && (memcmp(a.p, b.p, 24) || a.radius != b.radius || memcmp(a.n0, b.n0, 72))) return 10 + i;
+        if (a.type == RT355_OBJ_MESH && (a.tri_begin != b.tri_begin || a.tri_count != b.tri_count)) return 10 + i;
+        if ((a.tex0 >= 0) != (b.tex0 >= 0) || (a.tex1 >= 0) != (b.tex1 >= 0)) return 10 + i;
+        if (a.tex0 >= 0) {
+            const rt355_texture &ta = d->textures[a.tex0], &tb = f.textures[b.tex0];
+            if (ta.width != tb.width || ta.height != tb.height || ta.sx != tb.sx || ta.sy != tb.sy || ta.rgb != tb.rgb) return 10 + i;
+        }
+    }
+    if (d->n_triangles && memcmp(d->triangles, f.triangles.data(), sizeof(rt355_triangle) * d->n_triangles)) return 3;
+    std::vector<light_src *> ls = make_lights(sh);
+    std::vector<rt355_light> back = rt355_lights(ls);
+    int rc = 0;
+    for (int i = 0; i < sh->n_lights; i++)
+        if (back[i].type != sh->lights[i].type || memcmp(back[i].position, sh->lights[i].position, 72)) rc = 4;
+    Shader shd(ls, Color(sh->ambient[0], sh->ambient[1], sh->ambient[2]),
+               Color(sh->specular[0], sh->specular[1], sh->specular[2]),
+               Color(sh->border[0], sh->border[1], sh->border[2]));
+    rt355_shader s2 = rt355_shader_of(shd, back);
+    if (memcmp(s2.ambient, sh->ambient, 3) || memcmp(s2.specular, sh->specular, 3) || memcmp(s2.border, sh->border, 3)) rc = 5;
+    for (light_src *l : ls) delete l;
+    return rc;
 }
 
 } // extern "C"

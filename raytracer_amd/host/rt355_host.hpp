@@ -1,0 +1,212 @@
+// rt355_host.hpp -- C++ host side above the C ABI (include/rt355.h).
+//
+// Mirrors the scene-building interface of liz425/RayTracer so that a main() written for the
+// reference (image_synthesis/main.cpp:526-642) reads the same here: Plane / Sphere / Mesh
+// with the reference's constructor argument order, light_src, Shader, Scene with the public
+// camera fields, and setPixels(scene, shader, alias).  These classes only HOLD data; all
+// rendering happens in librt355.so on the GPU.  Errors surface as rt355::Error (the reference
+// prints to cout and carries on; a GPU library should not).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rt355.h"
+
+namespace rt355 {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct Vector3D { double x = 0, y = 0, z = 0; Vector3D() {} Vector3D(double a, double b, double c) : x(a), y(b), z(c) {} };
+using Point3D = Vector3D;
+struct Vector2D { double x = 0, y = 0; Vector2D() {} Vector2D(double a, double b) : x(a), y(b) {} };
+
+// Normalize of vector3D.h:79-88 (same operation order: the light direction is stored normalised)
+inline Vector3D Normalize(Vector3D v) {
+    double l = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (l != 0) return Vector3D(v.x / l, v.y / l, v.z / l);
+    return v;
+}
+
+struct Color { // color.h:16-31
+    unsigned char r = 0, g = 0, b = 0;
+    Color() {}
+    Color(int r_, int g_, int b_) : r((unsigned char)r_), g((unsigned char)g_), b((unsigned char)b_) {}
+    explicit Color(unsigned int c) : r((c & 0xff0000) >> 16), g((c & 0xff00) >> 8), b(c & 0xff) {}
+};
+
+struct Texture { // a loaded texture.h Texture: texels in memory order, scale factors
+    std::vector<unsigned char> rgb; int width = 0, height = 0; double sx = 1, sy = 1;
+};
+
+class AnyObject { // anyobject.h:17-36
+public:
+    double IOR = 1, fresnel = 1, ks = 0;
+    int texture_type = 0;
+    std::vector<std::shared_ptr<Texture>> textures;
+    virtual ~AnyObject() {}
+    virtual const std::string GetObjectType() const = 0;
+    void AddTexture(std::shared_ptr<Texture> t) { textures.push_back(std::move(t)); }
+};
+
+class Plane : public AnyObject { // anyobject.h:40-93
+public:
+    Color clr; Point3D pi; Vector3D n0, ni;
+    Plane(Point3D pi_in, Vector3D ni_in, Vector3D n0_in, Color clr_in, double ks_in = 0)
+        : clr(clr_in), pi(pi_in), n0(n0_in), ni(ni_in) { ks = ks_in; }
+    const std::string GetObjectType() const override { return "Plane"; }
+};
+
+class Sphere : public AnyObject { // anyobject.h:97-164
+public:
+    Color clr; Point3D pCenter; double radius; Vector3D n0{1, 0, 0}, n1{0, 1, 0}, n2{0, 0, 1};
+    Sphere(Point3D c, double r, Color clr_in, Vector3D n0_in = {1, 0, 0}, Vector3D n1_in = {0, 1, 0},
+           Vector3D n2_in = {0, 0, 1}, double ks_in = 0)
+        : clr(clr_in), pCenter(c), radius(r), n0(n0_in), n1(n1_in), n2(n2_in) { ks = ks_in; }
+    const std::string GetObjectType() const override { return "Sphere"; }
+};
+
+struct Triangle { // anyobject.h:444-532 (data members only)
+    Point3D p0, p1, p2; Vector2D UV_p0{0, 0}, UV_p1{1, 0}, UV_p2{0, 1};
+    Triangle(Point3D a, Point3D b, Point3D c) : p0(a), p1(b), p2(c) {}
+    void SetUV(Vector2D t0, Vector2D t1, Vector2D t2) { UV_p0 = t0; UV_p1 = t1; UV_p2 = t2; }
+};
+
+class Mesh : public AnyObject { // anyobject.h:534-675; triangles are supplied, not parsed
+public:
+    Color clr{150, 200, 110};
+    std::vector<Triangle> triangles;
+    explicit Mesh(std::vector<Triangle> tris = {}, double ks_in = 0) : triangles(std::move(tris)) { ks = ks_in; }
+    const std::string GetObjectType() const override { return "Mesh"; }
+};
+
+struct light_src { // light.h:12-56
+    int type; Point3D position; Vector3D direction; Vector3D color;
+    light_src(int type_in, Point3D position_in, Vector3D direction_in, Vector3D color_in)
+        : type(type_in), position(position_in), direction(Normalize(direction_in)), color(color_in) {}
+};
+
+struct Shader { // shader.h:25-37
+    std::vector<light_src *> light;
+    Color ambient_color, specular_color, border_color;
+    Shader(std::vector<light_src *> l, Color a, Color s, Color b)
+        : light(std::move(l)), ambient_color(a), specular_color(s), border_color(b) {}
+};
+
+struct Scene { // main.cpp:215-265 (camera fields; SetCamera is done by the library)
+    Vector3D v_up{0, 0, 1}, v_view{0, 1, 0}; Point3D p_eye{0, -50, 0};
+    double dist = 5, s_x = 10, s_y = 10;
+    std::vector<AnyObject *> objs;
+};
+
+namespace detail {
+inline void put(double *d, const Vector3D &v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+inline void put(uint8_t *d, const Color &c) { d[0] = c.r; d[1] = c.g; d[2] = c.b; }
+inline void check(int rc, const char *what) {
+    if (rc != RT355_OK) throw Error(std::string(what) + ": " + rt355_last_error());
+}
+} // namespace detail
+
+// An uploaded scene.  Build once, render many frames (camera, lights and shader colours may change).
+class DeviceScene {
+public:
+    explicit DeviceScene(const std::vector<AnyObject *> &objs) {
+        std::vector<rt355_object> o; std::vector<rt355_triangle> t; std::vector<rt355_texture> x;
+        for (const AnyObject *a : objs) {
+            rt355_object q; std::memset(&q, 0, sizeof q);
+            q.ks = a->ks; q.fresnel = a->fresnel; q.ior = a->IOR; q.texture_type = a->texture_type;
+            q.tex0 = q.tex1 = -1;
+            if (auto p = dynamic_cast<const Plane *>(a)) {
+                q.type = RT355_OBJ_PLANE; detail::put(q.p, p->pi); detail::put(q.n, p->ni); detail::put(q.n0, p->n0);
+                detail::put(q.rgb, p->clr);
+            } else if (auto s = dynamic_cast<const Sphere *>(a)) {
+                q.type = RT355_OBJ_SPHERE; detail::put(q.p, s->pCenter); q.radius = s->radius;
+                detail::put(q.n0, s->n0); detail::put(q.n1, s->n1); detail::put(q.n2, s->n2); detail::put(q.rgb, s->clr);
+            } else if (auto m = dynamic_cast<const Mesh *>(a)) {
+                q.type = RT355_OBJ_MESH; detail::put(q.rgb, m->clr);
+                q.tri_begin = (int32_t)t.size(); q.tri_count = (int32_t)m->triangles.size();
+                for (const Triangle &tr : m->triangles) {
+                    rt355_triangle r;
+                    detail::put(r.p0, tr.p0); detail::put(r.p1, tr.p1); detail::put(r.p2, tr.p2);
+                    r.uv0[0] = tr.UV_p0.x; r.uv0[1] = tr.UV_p0.y; r.uv1[0] = tr.UV_p1.x; r.uv1[1] = tr.UV_p1.y;
+                    r.uv2[0] = tr.UV_p2.x; r.uv2[1] = tr.UV_p2.y;
+                    t.push_back(r);
+                }
+            } else {
+                throw Error("object type '" + a->GetObjectType() + "' is not on the accelerated path");
+            }
+            for (size_t k = 0; k < a->textures.size() && k < 2; k++) {
+                const Texture &tx = *a->textures[k];
+                rt355_texture r; r.rgb = tx.rgb.data(); r.sx = tx.sx; r.sy = tx.sy; r.width = tx.width; r.height = tx.height;
+                (k == 0 ? q.tex0 : q.tex1) = (int32_t)x.size();
+                x.push_back(r);
+            }
+            o.push_back(q);
+        }
+        rt355_scene_desc d; std::memset(&d, 0, sizeof d);
+        d.objects = o.data(); d.n_objects = (int32_t)o.size();
+        d.triangles = t.data(); d.n_triangles = (int32_t)t.size();
+        d.textures = x.data(); d.n_textures = (int32_t)x.size();
+        detail::check(rt355_scene_create(&d, &h_), "rt355_scene_create");
+    }
+    ~DeviceScene() { rt355_scene_destroy(h_); }
+    DeviceScene(const DeviceScene &) = delete;
+    DeviceScene &operator=(const DeviceScene &) = delete;
+    rt355_scene *handle() const { return h_; }
+private:
+    rt355_scene *h_ = nullptr;
+};
+
+// setPixels(Scene sce, Shader shd, int alias) of main.cpp:339-376; width, height and pixmap are
+// globals there (main.cpp:33-34) and arguments here.  Returns the ray statistics.
+inline rt355_stats setPixels(DeviceScene &dev, const Scene &sce, const Shader &shd, int alias, int width, int height,
+                             unsigned char *pixmap, int row_begin = 0, int row_end = 0) {
+    rt355_camera c;
+    detail::put(c.v_up, sce.v_up); detail::put(c.v_view, sce.v_view); detail::put(c.p_eye, sce.p_eye);
+    c.dist = sce.dist; c.s_x = sce.s_x; c.s_y = sce.s_y;
+    std::vector<rt355_light> ls;
+    for (const light_src *l : shd.light) {
+        rt355_light q; std::memset(&q, 0, sizeof q);
+        q.type = l->type; detail::put(q.position, l->position); detail::put(q.direction, l->direction);
+        detail::put(q.color, l->color);
+        ls.push_back(q);
+    }
+    rt355_shader s; std::memset(&s, 0, sizeof s);
+    s.lights = ls.data(); s.n_lights = (int32_t)ls.size();
+    detail::put(s.ambient, shd.ambient_color); detail::put(s.specular, shd.specular_color);
+    detail::put(s.border, shd.border_color);
+    rt355_opts o; std::memset(&o, 0, sizeof o);
+    o.width = width; o.height = height; o.alias = alias; o.row_begin = row_begin; o.row_end = row_end;
+    o.mode = RT355_MODE_FAST;
+    rt355_stats st; std::memset(&st, 0, sizeof st);
+    detail::check(rt355_render(dev.handle(), &c, &s, &o, pixmap, &st), "rt355_render");
+    return st;
+}
+
+// 24-bit BMP, bottom-up rows, B,G,R -- what SaveImage (main.cpp:456-517) produces, with a
+// correct 3-bytes-per-pixel size field and rows padded to 4 bytes.
+inline void SaveImage(const char *file, int width, int height, const unsigned char *pixmap) {
+    FILE *f = std::fopen(file, "wb");
+    if (!f) throw Error(std::string("cannot open ") + file);
+    const int row = (width * 3 + 3) & ~3;
+    const uint32_t data = (uint32_t)row * height, size = 54 + data;
+    unsigned char h[54]; std::memset(h, 0, sizeof h);
+    h[0] = 'B'; h[1] = 'M'; std::memcpy(h + 2, &size, 4); h[10] = 54; h[14] = 40;
+    std::memcpy(h + 18, &width, 4); std::memcpy(h + 22, &height, 4); h[26] = 1; h[28] = 24; std::memcpy(h + 34, &data, 4);
+    std::fwrite(h, 1, 54, f);
+    std::vector<unsigned char> line(row, 0);
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const unsigned char *p = pixmap + ((size_t)y * width + x) * 3;
+            line[3 * x] = p[2]; line[3 * x + 1] = p[1]; line[3 * x + 2] = p[0];
+        }
+        std::fwrite(line.data(), 1, row, f);
+    }
+    std::fclose(f);
+}
+
+} // namespace rt355

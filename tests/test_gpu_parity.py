@@ -156,3 +156,41 @@ def test_error_behaviour(api):
     with pytest.raises(api.Rt355Error, match="ARG"):
         r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, row_begin=40, row_end=20)
     r.close()
+
+
+def test_candidate_overflow_falls_back_to_brute_force(api, oracle):
+    """More than 32 spheres on one line of sight: the candidate list overflows and the ray is
+    re-done over all primitives in fp64 -- the frame must still be exact."""
+    sc = S.Scene()
+    sc.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+    for i in range(48):      # nested on the view axis, all hit by the central rays
+        sc.add_sphere((0.0, 5.0 + 0.75 * i, 0.0), 2.0 + 0.01 * i, (40 + 4 * i, 200 - 3 * i, 90))
+    for i in range(40):      # filler so that the search path (>= 64 primitives) is taken
+        sc.add_sphere((-30.0 + 1.5 * i, 60.0, 20.0), 0.5, (200, 200, 50))
+    sh = S.Shader([S.light_src(1, (0.0, -30.0, 0.5), (0, 0, -1), (1, 1, 1))], 0x101010, 0xDDDDDD, 0x000000)
+    w, h = 96, 64
+    cam = S.default_camera(w, h)
+    want, _ = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    r = api.Renderer(sc)
+    got, st = r.render(cam, sh, w, h)
+    r.close()
+    assert st["overflow_rays"] > 0
+    _compare(got, want)
+
+
+def test_cpp_host_demo_matches_checker(api, oracle, tmp_path):
+    """raytracer_amd/host/rt355_demo (C++ mirror of the reference main()) end to end."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracer_amd", "host", "rt355_demo")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    prefix = str(tmp_path / "demo")
+    subprocess.run([exe, "320", "240", "2", prefix], check=True, timeout=100)
+    got = np.fromfile(prefix + ".rgb", dtype=np.uint8).reshape(240, 320, 3)
+    want, _ = oracle.render(S.default_scene().pack(), S.default_camera(320, 240), S.default_shader(2),
+                            B.opts(320, 240), threads=0)
+    _compare(got, want)
+    bmp = open(prefix + ".bmp", "rb").read()
+    assert bmp[:2] == b"BM" and len(bmp) == 54 + 320 * 240 * 3
+    # BMP rows are bottom-up B,G,R: first pixel of the file = pixel (0,0) of the pixmap
+    assert list(bmp[54:57]) == list(want[0, 0][::-1])

@@ -1,0 +1,80 @@
+"""CPU, world size 2 over gloo: the slab partition + final-frame gather and the round-robin
+frame partition reproduce the single-process frame.  Slabs are rendered by the CPU checker here
+(the GPU test test_slabs_equal_whole_frame covers the HIP side of the same partition)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle.oracle_py import Oracle
+    from raytracer_amd import binding as B
+    from raytracer_amd import scenes as S
+    from raytracer_amd.sharding import frames_for_rank, gather_frame, slab_rows
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O = Oracle()
+    sc, sh, cam, w, h = S.small_case("default_2lights")
+    p = sc.pack()
+    b, e = slab_rows(h, world)[rank]
+    local = np.zeros((h, w, 3), dtype=np.uint8)
+    O.render(p, cam, sh, B.opts(w, h, row_begin=b, row_end=e), threads=2, out=local)
+    full = gather_frame(torch.from_numpy(local), rank, world, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "slabs.npy"), full.numpy())
+    else:
+        assert full is None
+    # camera sweep: frame f on rank f mod world, hashes exchanged only to check the partition
+    mine = frames_for_rank(5, rank, world)
+    hashes = torch.zeros(5, dtype=torch.int64)
+    for f in mine:
+        frame, _ = O.render(p, S.orbit_camera(f, 48, 32, n_frames=5, center=(0, 0, 0), radius=30, eye_z=8), sh,
+                            B.opts(48, 32), threads=2)
+        hashes[f] = O.fnv(frame) & 0x7FFFFFFFFFFFFFFF
+    dist.all_reduce(hashes)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "sweep.npy"), hashes.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slabs_and_sweep_world2(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    from raytracer_amd import binding as B
+    from raytracer_amd import scenes as S
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sc, sh, cam, w, h = S.small_case("default_2lights")
+    want, _ = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=2)
+    got = np.load(tmp_path / "slabs.npy")
+    assert np.array_equal(got, want)
+    sweep = np.load(tmp_path / "sweep.npy")
+    for f in range(5):
+        frame, _ = oracle.render(sc.pack(), S.orbit_camera(f, 48, 32, n_frames=5, center=(0, 0, 0), radius=30, eye_z=8),
+                                 sh, B.opts(48, 32), threads=2)
+        assert int(sweep[f]) == oracle.fnv(frame) & 0x7FFFFFFFFFFFFFFF
+
+
+def test_slab_rows_cover_frame():
+    from raytracer_amd.sharding import frames_for_rank, slab_rows
+    for h in (1, 7, 600, 2160, 4320):
+        for n in (1, 2, 3, 4, 8):
+            if n > h:
+                continue
+            rows = slab_rows(h, n)
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(n - 1))
+            sizes = [e - b for b, e in rows]
+            assert max(sizes) - min(sizes) <= 1
+    assert sorted(sum((frames_for_rank(60, r, 8) for r in range(8)), [])) == list(range(60))
+    with pytest.raises(ValueError):
+        slab_rows(0, 2)
