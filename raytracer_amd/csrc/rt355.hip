@@ -159,6 +159,90 @@ __global__ void k_bundle_origin(SceneView s, d3 O, int is_eye, int n_padded, flo
     L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
 }
 
+// Bundle of parallel rays (the shadow rays of a directional light, shader.h:76-77): every ray
+// runs along w = -direction.  With an orthonormal basis (e1, e2, w), "ray from ph hits sphere
+// (c, r)" needs the 2-D distance between the projections of ph and c to be <= r, and "hits
+// triangle" needs the projection of ph inside the projected triangle.
+//   L1[i] = (u_c, v_c, R2, 0): projected centre and inflated squared radius of primitive i's
+//           bounding circle; R2 = +inf "always" (planes), -inf "never" (culled, padding).
+//   L2[3i..3i+2] = (A, B, C, 0): inward unit edge functions A*u + B*v + C of the projected
+//           triangle, C already raised by the per-primitive rounding bound.  Zero rows pass.
+// A ray carries (u_p, v_p, m_sq, m_lin): its projected origin and the two bounds that cover the
+// fp32 rounding of its own coordinates (they grow with |u_p| + |v_p|; hit points on a plane can
+// lie far from the scene).
+struct Bundle {
+    int kind;     // 0 = not searched (fp64 brute force), 1 = common origin, 2 = common direction
+    d3 o;         // kind 1: the origin
+    d3 e1, e2;    // kind 2: basis of the projection plane
+    double rmaxp; // kind 2: upper bound of (bounding radius + per-primitive rounding bound)
+};
+#define RT_EPS22 2.384185791015625e-07 /* 2^-22 */
+
+__global__ void k_bundle_direction(SceneView s, Bundle bd, d3 w, int n_padded, float4 *__restrict__ L1,
+                                   float4 *__restrict__ L2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_padded) return;
+    const float inf = __builtin_inff();
+    float4 never = make_float4(0.f, 0.f, -inf, 0.f), always = make_float4(0.f, 0.f, inf, 0.f);
+    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 l1 = never, a = z4, b = z4, c = z4;
+    if (i < s.n_prims) {
+        int obj = s.prim_obj[i], tri = s.prim_tri[i];
+        d3 ctr; double rad = 0; bool round_like = false;
+        if (tri < 0) {
+            const DObject &o = s.objects[obj];
+            if (o.type == RT_OBJ_PLANE) {
+                // Plane::CalcIntersect misses when ni . npe >= 0 (anyobject.h:80); npe = w up to rounding
+                d3 ni = ld3(o.n);
+                l1 = (dot(ni, w) > 1e-12 * vlen(ni)) ? never : always;
+            } else { ctr = ld3(o.p); rad = fabs(o.radius); round_like = true; }
+        } else {
+            const DTriangle &t = s.tris[tri];
+            d3 p0 = ld3(t.p0), p1 = ld3(t.p1), p2 = ld3(t.p2), nrm = ld3(t.normal), pc = ld3(t.p_center);
+            if (!(dot(nrm, w) > 1e-12)) { // back-face test of anyobject.h:490 is the same for every ray
+                ctr = pc;
+                rad = fmax(vlen(vsub(p0, pc)), fmax(vlen(vsub(p1, pc)), vlen(vsub(p2, pc))));
+                round_like = true;
+                double u[3] = {dot(p0, bd.e1), dot(p1, bd.e1), dot(p2, bd.e1)};
+                double v[3] = {dot(p0, bd.e2), dot(p1, bd.e2), dot(p2, bd.e2)};
+                double area2 = (u[1] - u[0]) * (v[2] - v[0]) - (v[1] - v[0]) * (u[2] - u[0]);
+                double big = fabs(u[0]) + fabs(v[0]) + fabs(u[1]) + fabs(v[1]) + fabs(u[2]) + fabs(v[2]);
+                if (fabs(area2) > 1e-12 * (rad * rad + 1e-300)) {
+                    float4 rows[3];
+                    for (int k = 0; k < 3; k++) {
+                        int q = (k + 1) % 3, r = (k + 2) % 3;
+                        double A = -(v[q] - v[k]), B = (u[q] - u[k]);
+                        double len = sqrt(A * A + B * B);
+                        A /= len; B /= len;
+                        double side = A * (u[r] - u[k]) + B * (v[r] - v[k]);
+                        if (side < 0) { A = -A; B = -B; }
+                        double C = -(A * u[k] + B * v[k]) + 4.0 * RT_EPS22 * big + 1e-6 * rad + 1e-30;
+                        rows[k] = make_float4((float)A, (float)B, (float)C, 0.f);
+                    }
+                    a = rows[0]; b = rows[1]; c = rows[2];
+                }
+            }
+        }
+        if (round_like) {
+            double uc = dot(ctr, bd.e1), vc = dot(ctr, bd.e2);
+            double es = RT_EPS22 * (fabs(uc) + fabs(vc) + rad);
+            double R = rad + es;
+            l1 = make_float4((float)uc, (float)vc, (float)(R * R * (1.0 + 1e-6)), 0.f);
+        }
+    }
+    L1[i] = l1;
+    L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
+}
+
+// fp32 search record of a shadow ray for the given bundle
+__device__ __forceinline__ float4 bundle_ray(const Bundle &bd, d3 ph, d3 nhl) {
+    if (bd.kind == 1) return make_float4((float)nhl.x, (float)nhl.y, (float)nhl.z, 0.f);
+    double pu = dot(ph, bd.e1), pv = dot(ph, bd.e2);
+    double er = RT_EPS22 * (fabs(pu) + fabs(pv));
+    double msq = (2.0 * bd.rmaxp * er + er * er) * (1.0 + 1e-5);
+    return make_float4((float)pu, (float)pv, (float)(msq * (1.0 + 1e-6)), (float)(4.0 * er));
+}
+
 // ---- camera rays -------------------------------------------------------------------------------------
 __global__ void k_gen_primary(DCamera cam, Frame f, float4 *__restrict__ ray32) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,23 +342,38 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 
 // and survivors are appended to the rays' candidate lists in primitive order.
 #define SEARCH_GROUP 4
 
-__device__ __forceinline__ float cone_margin(float dx, float dy, float dz, const float4 &p) {
-    return __builtin_fmaf(dz, p.z, __builtin_fmaf(dy, p.y, __builtin_fmaf(dx, p.x, p.w)));
+// margin >= 0 (kind 1) / margin >= -m_sq (kind 2)  <=>  the pair is a candidate
+template <int KIND>
+__device__ __forceinline__ float pair_margin(float x, float y, float z, const float4 &p) {
+    if (KIND == 1) return __builtin_fmaf(z, p.z, __builtin_fmaf(y, p.y, __builtin_fmaf(x, p.x, p.w)));
+    float du = p.x - x, dv = p.y - y;
+    return __builtin_fmaf(-dv, dv, __builtin_fmaf(-du, du, p.z));
 }
 
-__device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t prim, float dx, float dy,
-                                                 float dz, uint32_t rid, uint32_t n_rays, uint32_t *cand,
+template <int KIND>
+__device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t prim, float x, float y,
+                                                 float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
                                                  uint32_t &cnt) {
     const float4 a = L2[3 * (size_t)prim], b = L2[3 * (size_t)prim + 1], c = L2[3 * (size_t)prim + 2];
-    float ea = __builtin_fmaf(dz, a.z, __builtin_fmaf(dy, a.y, dx * a.x));
-    float eb = __builtin_fmaf(dz, b.z, __builtin_fmaf(dy, b.y, dx * b.x));
-    float ec = __builtin_fmaf(dz, c.z, __builtin_fmaf(dy, c.y, dx * c.x));
-    if (fminf(ea, fminf(eb, ec)) >= -1e-6f) {
+    float ea, eb, ec, floor_;
+    if (KIND == 1) { // direction inside the pyramid over the triangle
+        ea = __builtin_fmaf(z, a.z, __builtin_fmaf(y, a.y, x * a.x));
+        eb = __builtin_fmaf(z, b.z, __builtin_fmaf(y, b.y, x * b.x));
+        ec = __builtin_fmaf(z, c.z, __builtin_fmaf(y, c.y, x * c.x));
+        floor_ = -1e-6f;
+    } else {         // projected origin inside the projected triangle
+        ea = __builtin_fmaf(y, a.y, __builtin_fmaf(x, a.x, a.z));
+        eb = __builtin_fmaf(y, b.y, __builtin_fmaf(x, b.x, b.z));
+        ec = __builtin_fmaf(y, c.y, __builtin_fmaf(x, c.x, c.z));
+        floor_ = -lin;
+    }
+    if (fminf(ea, fminf(eb, ec)) >= floor_) {
         if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = prim;
         cnt++;
     }
 }
 
+template <int KIND>
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restrict__ L1,
                                                            const float4 *__restrict__ L2, int n_padded,
                                                            const float4 *__restrict__ ray32, uint32_t n_rays,
@@ -289,15 +388,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
     // takes entries [1024 b, 1024 b + 1024) of the compacted list and retires if there are none.
     const uint32_t total = active_rid ? *n_active : n_rays;
     if (blockIdx.x * RAYS_PER_TILE >= total) return;
-    float dx[RAYS_PER_THREAD], dy[RAYS_PER_THREAD], dz[RAYS_PER_THREAD];
+    float rx[RAYS_PER_THREAD], ry[RAYS_PER_THREAD], rz[RAYS_PER_THREAD], rw[RAYS_PER_THREAD];
     uint32_t cnt[RAYS_PER_THREAD], rid[RAYS_PER_THREAD];
+    float floor_lane = 0.0f; // kind 2: the loosest -m_sq of this lane's rays
 #pragma unroll
     for (int r = 0; r < RAYS_PER_THREAD; r++) {
         const uint32_t slot = base + r * SEARCH_THREADS;
         const bool live = slot < total;
         rid[r] = active_rid ? (live ? active_rid[slot] : 0u) : slot;
         float4 q = live ? ray32[rid[r]] : nan4();
-        dx[r] = q.x; dy[r] = q.y; dz[r] = q.z; cnt[r] = 0;
+        rx[r] = q.x; ry[r] = q.y; rz[r] = q.z; rw[r] = q.w; cnt[r] = 0;
+        if (KIND == 2) floor_lane = fminf(floor_lane, -q.z);
     }
     const int n_tiles = n_padded / PRIM_TILE;
     float4 s0 = L1[t], s1 = L1[t + SEARCH_THREADS];
@@ -321,20 +422,20 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
             const int jn = (j + SEARCH_GROUP) & (PRIM_TILE - 1); // the last prefetch wraps; its values are unused
 #pragma unroll
             for (int g = 0; g < SEARCH_GROUP; g++) nxt[g] = tile_lds[jn + g];
-            float top = -3.0e38f;
+            float top = -__builtin_inff();
 #pragma unroll
             for (int g = 0; g < SEARCH_GROUP; g++) {
 #pragma unroll
-                for (int r = 0; r < RAYS_PER_THREAD; r++) top = fmaxf(top, cone_margin(dx[r], dy[r], dz[r], p[g]));
+                for (int r = 0; r < RAYS_PER_THREAD; r++) top = fmaxf(top, pair_margin<KIND>(rx[r], ry[r], rz[r], p[g]));
             }
-            if (__builtin_expect(top >= 0.0f, 0)) {
+            if (__builtin_expect(top >= floor_lane, 0)) {
 #pragma unroll
                 for (int g = 0; g < SEARCH_GROUP; g++) {
                     const uint32_t prim = (uint32_t)(tile * PRIM_TILE + j + g);
 #pragma unroll
                     for (int r = 0; r < RAYS_PER_THREAD; r++)
-                        if (cone_margin(dx[r], dy[r], dz[r], p[g]) >= 0.0f)
-                            append_candidate(L2, prim, dx[r], dy[r], dz[r], rid[r], n_rays, cand, cnt[r]);
+                        if (pair_margin<KIND>(rx[r], ry[r], rz[r], p[g]) >= (KIND == 2 ? -rz[r] : 0.0f))
+                            append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
                 }
             }
         }
@@ -385,7 +486,7 @@ __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, 
 }
 
 // Colour of light k before CalcShadow (shader.h:75-89) and the shadow ray it needs.
-__device__ __forceinline__ uint32_t light_prepare(const ShaderView &sh, int k, bool searched, d3 pe, d3 ph, d3 nh,
+__device__ __forceinline__ uint32_t light_prepare(const ShaderView &sh, int k, const Bundle &bd, d3 pe, d3 ph, d3 nh,
                                               d3 npe, uint32_t cm0, uint32_t cm1, bool no_border, uint32_t rid,
                                               const Work &w) {
     const DLight &L = sh.lights[k];
@@ -395,12 +496,12 @@ __device__ __forceinline__ uint32_t light_prepare(const ShaderView &sh, int k, b
     if (!no_border) clr = calc_border(sh, clr, pe, ph, nh);
     bool needs = !(dot(nh, vmul(nhl, -1)) <= 0); // shader.h:396
     w.rec_pre[rid] = clr | (needs ? (1u << 24) : 0u);
-    if (searched) w.ray32[rid] = needs ? make_float4((float)nhl.x, (float)nhl.y, (float)nhl.z, 0.f) : nan4();
+    if (bd.kind) w.ray32[rid] = needs ? bundle_ray(bd, ph, nhl) : nan4();
     return needs ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
-                                                         int brute, int next_searched,
+                                                         int brute, Bundle next,
                                                          unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_shadow = 0, n_eval = 0, n_over = 0;
@@ -410,7 +511,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (!(x < f.width && y < f.rows)) {
         w.rec_obj[rid] = -2;
-        if (next_searched) w.ray32[rid] = nan4();
+        if (next.kind) w.ray32[rid] = nan4();
         break;
     }
     Ray e = calc_view(cam, (double)x / (double)f.width, (double)(y + f.row_begin) / (double)f.height);
@@ -418,7 +519,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
         w.rec_obj[rid] = -1;
-        if (next_searched) w.ray32[rid] = nan4();
+        if (next.kind) w.ray32[rid] = nan4();
         if (sh.n_lights == 0) store_pixel(pixmap, f, x, y, 0u);
         break;
     }
@@ -461,7 +562,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_cm0[rid] = cm0 | (no_border ? (1u << 24) : 0u);
     w.rec_cm1[rid] = cm1;
     w.rec_sum[rid] = 0u;
-    n_shadow = light_prepare(sh, 0, next_searched != 0, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w);
+    n_shadow = light_prepare(sh, 0, next, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w);
     } while (0);
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
@@ -471,7 +572,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
 // CalcShadow for light k (shader.h:393-433), the running mean (shader.h:93), then either the next
 // light's pre-shadow colour or the pixel store (main.cpp:367-369).
 __global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
-                                                       int k, int brute, int next_searched,
+                                                       int k, int brute, Bundle next,
                                                        unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_shadow = 0, n_eval = 0, n_over = 0;
@@ -511,7 +612,7 @@ __global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView s
     d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
     d3 npe = D3(w.rec_d[6 * n + rid], w.rec_d[7 * n + rid], w.rec_d[8 * n + rid]);
     uint32_t cm0 = w.rec_cm0[rid];
-    n_shadow = light_prepare(sh, k + 1, next_searched != 0, ld3(cam.p_eye), ph, nh, npe, cm0 & 0xffffffu,
+    n_shadow = light_prepare(sh, k + 1, next, ld3(cam.p_eye), ph, nh, npe, cm0 & 0xffffffu,
                              w.rec_cm1[rid], (cm0 >> 24) & 1u, rid, w);
     } while (0);
     wave_count(w.counters, 0, n_shadow);
@@ -592,6 +693,8 @@ struct rt355_scene {
     SceneView view{};
     int n_padded = 0;
     bool has_tris = false;
+    double rmax = 0;   // largest sphere radius / triangle bounding radius
+    double extent = 0; // largest |coordinate| of a sphere centre or triangle vertex
     // owned device allocations of the scene
     std::vector<void *> owned;
     // per-render bundle tables and per-ray workspace (grown on demand)
@@ -607,7 +710,6 @@ struct rt355_scene {
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
     uint64_t pending_primary = 0, pending_pairs_static = 0;
-    std::vector<int> pending_searched; // per bundle: 1 if searched
     int pending_nprims = 0;
     bool pending = false;
 };
@@ -634,6 +736,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     std::vector<DObject> objs(d->n_objects);
     std::vector<DTriangle> tris(d->n_triangles);
     std::vector<int32_t> prim_obj, prim_tri;
+    double rmax = 0, extent = 0;
     for (int i = 0; i < d->n_objects; i++) {
         const rt355_object &o = d->objects[i];
         if (o.type != RT355_OBJ_PLANE && o.type != RT355_OBJ_SPHERE && o.type != RT355_OBJ_MESH)
@@ -653,6 +756,10 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         q.type = o.type; q.texture_type = o.texture_type; q.tex0 = o.tex0; q.tex1 = o.tex1;
         q.tri_begin = o.tri_begin; q.tri_count = o.tri_count;
         q.rgb = pack_rgb(o.rgb);
+        if (o.type == RT355_OBJ_SPHERE) {
+            rmax = std::max(rmax, fabs(o.radius));
+            for (int a = 0; a < 3; a++) extent = std::max(extent, fabs(o.p[a]));
+        }
         if (o.type == RT355_OBJ_MESH) {
             if (o.tri_begin < 0 || o.tri_count < 0 || (int64_t)o.tri_begin + o.tri_count > d->n_triangles)
                 return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": triangle range out of bounds");
@@ -670,6 +777,12 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         q.p_center[0] = (p0.x + p1.x + p2.x) / 3.0; q.p_center[1] = (p0.y + p1.y + p2.y) / 3.0;
         q.p_center[2] = (p0.z + p1.z + p2.z) / 3.0;
         memcpy(q.uv0, t.uv0, sizeof q.uv0); memcpy(q.uv1, t.uv1, sizeof q.uv1); memcpy(q.uv2, t.uv2, sizeof q.uv2);
+        h3 pc = H3(q.p_center);
+        for (h3 v : {p0, p1, p2}) {
+            h3 e = hsub(v, pc);
+            rmax = std::max(rmax, sqrt(e.x * e.x + e.y * e.y + e.z * e.z));
+            extent = std::max(extent, std::max(fabs(v.x), std::max(fabs(v.y), fabs(v.z))));
+        }
     }
     std::vector<DTexture> tex(d->n_textures);
     std::vector<uint8_t> pool;
@@ -693,6 +806,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
     if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
     sc->has_tris = d->n_triangles > 0;
+    sc->rmax = rmax; sc->extent = extent;
     HIP_TRY(hipEventCreate(&sc->ev_begin));
     HIP_TRY(hipEventCreate(&sc->ev_end));
     void *ctr = nullptr;
@@ -819,11 +933,33 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     sh.ambient = pack_rgb(shader->ambient); sh.specular = pack_rgb(shader->specular); sh.border = pack_rgb(shader->border);
     DCamera dc = set_camera(cam);
 
-    // which bundles are searched: bundle 0 = camera rays, bundle 1+k = shadow rays of light k
+    // bundle 0 = camera rays (common origin: the eye); bundle 1+k = shadow rays of light k (common
+    // origin: the light position, or common direction for a directional light)
     const bool can_search = (opts->mode == RT355_MODE_FAST) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
-    std::vector<int> searched(1 + nl, 0);
-    searched[0] = can_search;
-    for (int k = 0; k < nl; k++) searched[1 + k] = can_search && hl[k].type != 0; // directional: brute for now
+    std::vector<Bundle> bundles(2 + nl);
+    std::vector<d3> ray_dir(2 + nl);
+    for (auto &b : bundles) memset(&b, 0, sizeof b);
+    if (can_search) {
+        bundles[0].kind = 1;
+        bundles[0].o.x = dc.p_eye[0]; bundles[0].o.y = dc.p_eye[1]; bundles[0].o.z = dc.p_eye[2];
+        for (int k = 0; k < nl; k++) {
+            Bundle &b = bundles[1 + k];
+            if (hl[k].type != 0) {
+                b.kind = 1;
+                b.o.x = hl[k].position[0]; b.o.y = hl[k].position[1]; b.o.z = hl[k].position[2];
+            } else {
+                h3 w = hnormalize(hmul(H3(hl[k].direction), -1.0)); // shadow rays run along -direction (shader.h:395)
+                if (w.x == 0 && w.y == 0 && w.z == 0) continue;     // degenerate light: leave it to the fp64 walk
+                h3 a = (fabs(w.x) <= fabs(w.y) && fabs(w.x) <= fabs(w.z)) ? h3{1, 0, 0}
+                       : (fabs(w.y) <= fabs(w.z) ? h3{0, 1, 0} : h3{0, 0, 1});
+                h3 e1 = hnormalize(hcross(w, a)), e2 = hcross(w, e1);
+                b.kind = 2;
+                b.e1.x = e1.x; b.e1.y = e1.y; b.e1.z = e1.z; b.e2.x = e2.x; b.e2.y = e2.y; b.e2.z = e2.z;
+                b.rmaxp = sc->rmax * (1.0 + 1e-6) + 8.0 * 2.384185791015625e-07 * (sc->extent + sc->rmax) + 1e-30;
+                ray_dir[1 + k].x = w.x; ray_dir[1 + k].y = w.y; ray_dir[1 + k].z = w.z;
+            }
+        }
+    }
 
     HIP_TRY(hipEventRecord(sc->ev_begin, st));
     HIP_TRY(hipMemsetAsync(sc->work.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
@@ -832,8 +968,13 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     const unsigned n_tiles = (unsigned)(f.tiles_x * f.tiles_y);
     unsigned char *pix = (unsigned char *)d_pixmap;
     int launches = 0;
-    auto run_search = [&](d3 origin, int is_eye) -> int {
-        hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, origin, is_eye, sc->n_padded, sc->L1, sc->L2);
+    auto run_search = [&](int bi) -> int {
+        const Bundle &b = bundles[bi];
+        const bool is_eye = (bi == 0);
+        if (b.kind == 1)
+            hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, b.o, is_eye ? 1 : 0, sc->n_padded, sc->L1, sc->L2);
+        else
+            hipLaunchKernelGGL(k_bundle_direction, dim3(setup_blocks), dim3(256), 0, st, sc->view, b, ray_dir[bi], sc->n_padded, sc->L1, sc->L2);
         const uint32_t *list = nullptr, *total = nullptr;
         if (!is_eye) { // shadow bundles are sparse: compact their active rays first
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count);
@@ -842,25 +983,24 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             list = sc->work.active_rid; total = sc->work.tile_count + n_tiles;
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
-        hipLaunchKernelGGL(k_search, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
+        if (b.kind == 1)
+            hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
+        else
+            hipLaunchKernelGGL(k_search<2>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
         launches++;
         return RT355_OK;
     };
-    if (searched[0]) {
+    if (bundles[0].kind) {
         hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, sc->work.ray32);
-        d3 eye; eye.x = dc.p_eye[0]; eye.y = dc.p_eye[1]; eye.z = dc.p_eye[2];
-        if ((rc = run_search(eye, 1))) return rc;
+        if ((rc = run_search(0))) return rc;
     }
     hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work,
-                       searched[0] ? 0 : 1, nl > 0 ? searched[1] : 0, pix);
+                       bundles[0].kind ? 0 : 1, bundles[1], pix);
     for (int k = 0; k < nl; k++) {
-        if (searched[1 + k]) {
-            d3 o; o.x = hl[k].position[0]; o.y = hl[k].position[1]; o.z = hl[k].position[2];
-            if ((rc = run_search(o, 0))) return rc;
-        }
+        if (bundles[1 + k].kind && (rc = run_search(1 + k))) return rc;
         hipLaunchKernelGGL(k_light_resolve, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work, k,
-                           searched[1 + k] ? 0 : 1, (k + 1 < nl) ? searched[2 + k] : 0, pix);
+                           bundles[1 + k].kind ? 0 : 1, bundles[2 + k], pix);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, st));
@@ -868,7 +1008,6 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     sc->pending_stats = stats;
     sc->pending_stream = st;
     sc->pending_primary = (uint64_t)f.width * f.rows;
-    sc->pending_searched = searched;
     sc->pending_nprims = sc->view.n_prims;
     sc->search_launches = launches;
     return RT355_OK;

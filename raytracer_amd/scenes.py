@@ -237,6 +237,25 @@ def small_case(name: str):
         w, h = 160, 120
         s = spheres_scene(300, seed=77)
         return s, Shader(ring_lights(3), 0x101010, 0xDDDDDD, 0x202020), default_camera(w, h), w, h
+    if name == "spheres300_dir":
+        # directional + spot + point light over enough primitives to take the search path
+        w, h = 160, 120
+        s = spheres_scene(300, seed=78)
+        sh = Shader([light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 1, 1)),
+                     light_src(2, (0, 20, 90), (0.1, 0.5, -1), (1, 0.9, 0.8)),
+                     light_src(0, (50, 0, 100), (0.3, 0.2, -1), (0.6, 0.7, 1.0))], 0x101010, 0xDDDDDD, 0x202020)
+        return s, sh, default_camera(w, h), w, h
+    if name == "mesh_dir":
+        # mesh + spheres lit by a directional light coming from below the height field's front side
+        w, h = 128, 96
+        s = Scene()
+        s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+        m = s.add_mesh(_grid_mesh(8, 41), (150, 200, 110))
+        s.add_sphere((-6, 2, 1), 2.5, (100, 200, 100))
+        s.add_sphere((5, 6, 4), 2.0, (200, 100, 100))
+        sh = Shader([light_src(0, (0, -50, 100), (0.2, 0.6, -1), (1, 1, 1)),
+                     light_src(0, (0, 0, -100), (0, 0.1, 1), (1, 1, 1))], 0x000000, 0xDDDDDD, 0x000000)
+        return s, sh, default_camera(w, h), w, h
     if name == "inside":
         # eye inside a big sphere, a light inside another, overlapping spheres, a plane behind the eye
         w, h = 120, 90
@@ -253,4 +272,4 @@ def small_case(name: str):
 
 
 SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
-               "mesh_flat", "spheres300", "inside"]
+               "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside"]

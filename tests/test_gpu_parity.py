@@ -80,9 +80,14 @@ def test_probe_intersections_bit_exact(api, golden_dir):
 
 def test_mid_size_scenes_vs_checker(api, oracle):
     """Search path on scenes big enough to exercise several LDS tiles and many candidates."""
+    dir_lights = [S.light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 1, 1)),
+                  S.light_src(0, (40, 10, 100), (0.4, 0.3, -1), (1, 1, 1)),
+                  S.light_src(2, (0, 20, 90), (0.1, 0.5, -1), (1, 0.9, 0.8))]
     cases = [
         (S.spheres_scene(3000, seed=5), S.Shader(S.ring_lights(4), 0x101010, 0xDDDDDD, 0x000000), 256, 160),
         (S.mesh_scene(4000, seed=9, tex_size=64), S.mesh_shader(), 224, 128),
+        (S.spheres_scene(2500, seed=6), S.Shader(dir_lights, 0x101010, 0xDDDDDD, 0x000000), 224, 144),
+        (S.mesh_scene(3000, seed=10, tex_size=64), S.Shader(dir_lights[:2], 0x101010, 0xDDDDDD, 0x000000), 192, 128),
     ]
     for sc, sh, w, h in cases:
         cam = S.default_camera(w, h)
@@ -194,3 +199,49 @@ def test_cpp_host_demo_matches_checker(api, oracle, tmp_path):
     assert bmp[:2] == b"BM" and len(bmp) == 54 + 320 * 240 * 3
     # BMP rows are bottom-up B,G,R: first pixel of the file = pixel (0,0) of the pixmap
     assert list(bmp[54:57]) == list(want[0, 0][::-1])
+
+
+def _random_case(seed):
+    """A random mix of planes, spheres and meshes lit by random lights of every type."""
+    rng = S.SplitMix64(9000 + seed)
+    sc = S.Scene()
+    if rng.uniform() < 0.8:
+        sc.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+    if rng.uniform() < 0.5:
+        sc.add_plane((0, 40, 0), (0, -1, 0), (-1, 0, 0), (200, 200, 200))
+    n_sph = int(rng.uniform(20, 150))
+    for _ in range(n_sph):
+        c = (rng.uniform(-25, 25), rng.uniform(-5, 35), rng.uniform(-9, 15))
+        sc.add_sphere(c, rng.uniform(0.2, 3.5), (int(rng.uniform(30, 255)), int(rng.uniform(30, 255)), int(rng.uniform(30, 255))))
+    for m in range(int(rng.uniform(0, 3))):
+        n = int(rng.uniform(3, 9))
+        tris = S.heightfield_tris(n, n, seed=seed * 7 + m, x0=rng.uniform(-25, -5), x1=rng.uniform(5, 25),
+                                  y0=rng.uniform(-5, 5), y1=rng.uniform(10, 30), zbase=rng.uniform(-8, 4),
+                                  amp=rng.uniform(0.5, 4))
+        if rng.uniform() < 0.3:   # flip the winding of some meshes: back faces toward the camera
+            tris = tris[:, [0, 1, 2, 6, 7, 8, 3, 4, 5, 9, 10, 13, 14, 11, 12]]
+        sc.add_mesh(tris, (int(rng.uniform(30, 255)), 200, 110))
+    lights = []
+    for _ in range(int(rng.uniform(1, 4))):
+        t = int(rng.uniform(0, 4))
+        pos = (rng.uniform(-60, 60), rng.uniform(-40, 40), rng.uniform(10, 90))
+        d = (rng.uniform(-1, 1), rng.uniform(-1, 1), -rng.uniform(0.2, 1))
+        lights.append(S.light_src(t, pos, d, (rng.uniform(0.5, 1), rng.uniform(0.5, 1), rng.uniform(0.5, 1))))
+    sh = S.Shader(lights, 0x101418, 0xDDDDDD, 0x202020)
+    eye = (rng.uniform(-10, 10), rng.uniform(-30, -12), rng.uniform(-4, 12))
+    view = (rng.uniform(-0.3, 0.3), 1.0, rng.uniform(-0.3, 0.2))
+    w, h = 112, 80
+    return sc, sh, B.camera(eye, view, (0, 0, 1), 10.0, w, h), w, h
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes_search_is_conservative(api, oracle, seed):
+    """The fp32 search must never lose a pair the fp64 formulas accept: FAST == checker == BRUTE."""
+    sc, sh, cam, w, h = _random_case(seed)
+    assert sc.n_primitives >= 64
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    r = api.Renderer(sc)
+    got, st = r.render(cam, sh, w, h)
+    r.close()
+    _compare(got, want)
+    assert st["shadow_rays"] == wst["shadow_rays"]
