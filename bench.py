@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="spheres10k_8lights_4k")
     ap.add_argument("--shard", choices=["frames", "slabs"], default="frames")
+    ap.add_argument("--mode", choices=["fast", "packet"], default="fast",
+                    help="fast = all-pairs fp32 search; packet = per-wave beam culling before the pair tests")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -132,11 +134,12 @@ def main():
     r = Renderer(scene)
     fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     from raytracer_amd.sharding import gather_frame, slab_rows
+    mode = B.MODE_PACKET if args.mode == "packet" else B.MODE_FAST
     if args.shard == "slabs" and world > 1:
         b, e = slab_rows(h, world)[rank]
-        o = B.opts(w, h, row_begin=b, row_end=e)
+        o = B.opts(w, h, row_begin=b, row_end=e, mode=mode)
     else:
-        o = B.opts(w, h)
+        o = B.opts(w, h, mode=mode)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -183,7 +186,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if (args.shard == "frames" or world == 1) else "strong",
             "vs_baseline": None, "dtype": "f32 search + f64 resolve", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h, "primitives": scene.n_primitives,
-                       "lights": len(shader.lights), "alias": 0, "shard": args.shard,
+                       "lights": len(shader.lights), "alias": 0, "shard": args.shard, "search": args.mode,
                        "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"]},
                        "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"]},
         }

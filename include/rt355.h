@@ -116,6 +116,8 @@ typedef struct rt355_shader {
 /* ---- render options ------------------------------------------------------------------ */
 #define RT355_MODE_FAST  0 /* fp32 conservative candidate search + fp64 exact evaluation   */
 #define RT355_MODE_BRUTE 1 /* fp64 exact evaluation of every ray/primitive pair (debug)   */
+#define RT355_MODE_PACKET 2 /* as FAST, but each wave first culls the primitives against the
+                               beam of its 256 neighbouring rays; same candidates, same frame  */
 
 typedef struct rt355_opts {
     int32_t width, height; /* the reference's globals (main.cpp:33)                         */
@@ -132,6 +134,7 @@ typedef struct rt355_stats {
     uint64_t exact_tests;    /* pairs evaluated by the fp64 reference formulas              */
     uint64_t overflow_rays;  /* rays whose candidate list overflowed (re-done brute force)  */
     double   ms_device;      /* HIP-event time of the device work of this call              */
+    uint64_t packet_survivors; /* RT355_MODE_PACKET: (wave, primitive) pairs that passed the beam test */
 } rt355_stats;
 
 typedef struct rt355_scene rt355_scene; /* opaque, library-owned, bound to one HIP device */
@@ -170,6 +173,10 @@ int rt355_scene_search_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *la
  * and zeros on a miss).  Mirrors AnyObject::CalcIntersect (anyobject.h:23) one call at a time so
  * the device arithmetic can be checked in isolation. */
 int rt355_probe_intersect(rt355_scene *scene, int obj, const double *rays, int n, double *out);
+
+/* HIP-event duration (ms) of the index-th candidate-search launch of the last synced render
+ * (0 = camera rays, then one per searched light in light order). */
+int rt355_scene_search_launch_ms(rt355_scene *scene, int32_t index, double *ms);
 
 const char *rt355_last_error(void);
 int rt355_abi_version(void);

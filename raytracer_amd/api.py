@@ -14,7 +14,7 @@ import numpy as np
 
 from .binding import ERR, MODE_FAST, CStats, COpts, PackedScene, Scene, Shader, opts as make_opts
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt355.so")
+_LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt355.so")
 _lib = None
 
 
@@ -37,6 +37,7 @@ def lib():
         L.rt355_render_device.argtypes = [C.c_void_p] * 7
         L.rt355_scene_sync.argtypes = [C.c_void_p]
         L.rt355_scene_search_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.rt355_scene_search_launch_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
         L.rt355_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -93,6 +94,16 @@ class Renderer:
         ms, n = C.c_double(), C.c_int32()
         _check(lib().rt355_scene_search_kernel_ms(self.handle, C.byref(ms), C.byref(n)), "search_kernel_ms")
         return ms.value, n.value
+
+    def search_launch_ms(self):
+        """Per-launch durations (ms) of the last synced render's search kernels."""
+        _, n = self.search_kernel_ms()
+        out = []
+        for i in range(n):
+            ms = C.c_double()
+            _check(lib().rt355_scene_search_launch_ms(self.handle, i, C.byref(ms)), "search_launch_ms")
+            out.append(ms.value)
+        return out
 
     def probe_intersect(self, obj: int, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

@@ -31,26 +31,33 @@
 #include "rt_exact.h"
 
 #define RT_ABI_VERSION 1
-#define TILE_W 32           // pixels per tile edge; one workgroup searches one tile
-#define RAYS_PER_TILE 1024  // TILE_W * TILE_W
 #define SEARCH_THREADS 256
-#define RAYS_PER_THREAD 4
+#ifndef RAYS_PER_THREAD
+#define RAYS_PER_THREAD 4   // rays per lane of the search kernel (2, 4 or 8)
+#endif
+#define TILE_W 32                       // tile width in pixels; one workgroup searches one tile
+#define TILE_H (8 * RAYS_PER_THREAD)    // tile height in pixels
+#define RAYS_PER_TILE (SEARCH_THREADS * RAYS_PER_THREAD)
+#ifndef PRIM_TILE
 #define PRIM_TILE 512       // primitives staged in LDS per step (8 KiB, double buffered)
+#endif
 #define CAND_CAP 32         // candidate slots per ray; overflowing rays fall back to brute force
 #define SEARCH_MIN_PRIMS 64 // below this the fp64 brute-force walk is cheaper than a search
 
 // ---- rid <-> pixel -------------------------------------------------------------------------------
-// Rays are numbered tile-major ("rid"): rid = tile*1024 + r*256 + t, where search thread t of the
-// tile's workgroup owns rays r = 0..3.  Wave w of the workgroup covers a 16x16 pixel quarter of
-// the tile and each lane a 2x2 quad in it, so the 256 rays of a wave are neighbours on screen and
-// all per-ray buffers are read and written fully coalesced in every kernel.
+// Rays are numbered tile-major ("rid"): rid = tile*RAYS_PER_TILE + r*256 + t, where search thread
+// t of the tile's workgroup owns rays r = 0..RAYS_PER_THREAD-1.  Each lane owns a quad 2 pixels
+// wide and RAYS_PER_THREAD/2 high, each wave an 8x8 block of quads, and the four waves a 2x2
+// block of those, so the rays of a wave are neighbours on screen and all per-ray buffers are
+// read and written fully coalesced in every kernel.
+#define QUAD_H (RAYS_PER_THREAD / 2)
 __device__ __forceinline__ void rid_to_xy(uint32_t rid, int tiles_x, int *x, int *y) {
-    uint32_t tile = rid >> 10, local = rid & 1023u;
+    uint32_t tile = rid / RAYS_PER_TILE, local = rid % RAYS_PER_TILE;
     uint32_t r = local >> 8, t = local & 255u, wave = t >> 6, lane = t & 63u;
     int px = 16 * (int)(wave & 1u) + 2 * (int)(lane & 7u) + (int)(r & 1u);
-    int py = 16 * (int)(wave >> 1) + 2 * (int)(lane >> 3) + (int)(r >> 1);
+    int py = 8 * QUAD_H * (int)(wave >> 1) + QUAD_H * (int)(lane >> 3) + (int)(r >> 1);
     *x = (int)(tile % (uint32_t)tiles_x) * TILE_W + px;
-    *y = (int)(tile / (uint32_t)tiles_x) * TILE_W + py;
+    *y = (int)(tile / (uint32_t)tiles_x) * TILE_H + py;
 }
 
 struct Frame {
@@ -72,6 +79,7 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     unsigned long long *counters; // 0 shadow rays, 1 candidates evaluated, 2 overflow rays
     uint32_t *tile_count; // [tiles + 1] active rays per tile, then exclusive offsets; last = total
     uint32_t *active_rid; // [n] rids of the current bundle's active rays, tile-major order kept
+    uint32_t *bin_hist;   // [RT_BINS + 1] packet search: rays per direction bin, then offsets
 };
 
 // Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
@@ -330,6 +338,86 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 
     }
 }
 
+// ---- binning of a shadow bundle's rays by direction (packet search only) -----------------------------
+// Neighbouring pixels can have hit points far apart (depth edges, grazing floors), so the shadow
+// rays of a screen tile make a wide beam as seen from the light.  For the packet search the active
+// rays are therefore ordered by WHERE THEY POINT instead of where they are on screen: a counting
+// sort on a 256x256 grid over the sphere of directions (octahedral map) or over the projection
+// plane, cells numbered in Morton order so that consecutive cells are neighbours.  Order inside a
+// cell is whatever the atomics give; candidates are per ray, so frames do not depend on it.
+#define RT_BINS 65536
+// index of cell (x, y) of a 256x256 grid along the Hilbert curve: consecutive indices are always
+// neighbouring cells, so any run of consecutive rays covers one connected patch of directions
+__device__ __forceinline__ uint32_t hilbert8(uint32_t x, uint32_t y) {
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = 255u - x; y = 255u - y; }
+            uint32_t tmp = x; x = y; y = tmp;
+        }
+    }
+    return d;
+}
+template <int KIND>
+__device__ __forceinline__ uint32_t ray_bin(const float4 &q, float plane_extent) {
+    float u, v;
+    if (KIND == 1) { // octahedral map of the unit direction
+        float inv = 1.0f / (fabsf(q.x) + fabsf(q.y) + fabsf(q.z));
+        float px = q.x * inv, py = q.y * inv;
+        if (q.z < 0.f) {
+            float ox = (1.f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f);
+            float oy = (1.f - fabsf(px)) * (py >= 0.f ? 1.f : -1.f);
+            px = ox; py = oy;
+        }
+        u = px * 0.5f + 0.5f; v = py * 0.5f + 0.5f;
+    } else {         // grid over the projection plane; far-away origins share the border cells
+        u = q.x / plane_extent * 0.5f + 0.5f; v = q.y / plane_extent * 0.5f + 0.5f;
+    }
+    int ix = (int)fminf(fmaxf(u * 256.f, 0.f), 255.f), iy = (int)fminf(fmaxf(v * 256.f, 0.f), 255.f);
+    return hilbert8((uint32_t)ix, (uint32_t)iy);
+}
+// Rays of a wave mostly fall into a few cells, so the wave adds ONE atomic per distinct cell:
+// repeatedly take the cell of the first pending lane, ballot the lanes that share it, let the
+// leader add their count, and hand every such lane its rank.  Returns the value of the counter
+// before this wave's add plus the lane's rank (only meaningful for active lanes).
+__device__ __forceinline__ uint32_t wave_bin_add(uint32_t *__restrict__ counters, uint32_t bin, bool active) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t result = 0;
+    unsigned long long pending = __ballot(active);
+    while (pending) {
+        const int leader = __builtin_ctzll(pending);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(active && bin == b) & pending;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counters[b], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if ((same >> lane) & 1ull) result = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        pending &= ~same;
+    }
+    return result;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void k_bin_count(const float4 *__restrict__ ray32, uint32_t n_rays,
+                                                   float plane_extent, uint32_t *__restrict__ hist) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // n_rays is a multiple of the block size
+    float4 q = ray32[rid];
+    bool active = q.x == q.x;
+    wave_bin_add(hist, active ? ray_bin<KIND>(q, plane_extent) : 0u, active);
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void k_bin_scatter(const float4 *__restrict__ ray32, uint32_t n_rays,
+                                                     float plane_extent, uint32_t *__restrict__ offsets,
+                                                     uint32_t *__restrict__ active_rid) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 q = ray32[rid];
+    bool active = q.x == q.x;
+    uint32_t pos = wave_bin_add(offsets, active ? ray_bin<KIND>(q, plane_extent) : 0u, active);
+    if (active) active_rid[pos] = rid;
+}
+
 // ---- the all-pairs candidate search ------------------------------------------------------------------
 // One workgroup = one 32x32 pixel tile, 4 rays per lane.  The primitive stream is staged through
 // LDS in tiles of 512 cones (double buffered, one barrier per tile); every lane reads the same
@@ -340,7 +428,9 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 
 // is almost never taken (a wave's 16x16 pixels see a handful of the scene's cones), and when it
 // is, the group is re-examined pair by pair, the pyramid rows of the hit triangles are fetched,
 // and survivors are appended to the rays' candidate lists in primitive order.
+#ifndef SEARCH_GROUP
 #define SEARCH_GROUP 4
+#endif
 
 // margin >= 0 (kind 1) / margin >= -m_sq (kind 2)  <=>  the pair is a candidate
 template <int KIND>
@@ -447,6 +537,134 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
 #pragma unroll
     for (int r = 0; r < RAYS_PER_THREAD; r++)
         if (base + r * SEARCH_THREADS < total) cand_cnt[rid[r]] = cnt[r];
+}
+
+// ---- packet search: one beam test per (wave, primitive), pair tests only for the survivors -----------
+// The 256 rays of a wave are neighbours on screen, so they fit in a narrow beam: a cone around
+// their mean direction (common-origin bundles) or a disc around their mean projected origin
+// (common-direction bundles).  A primitive whose bounding cone / circle misses the beam cannot be a
+// candidate of any ray of the wave.  Lanes take 64 primitives at a time (one coalesced 1 KiB read
+// of the table per wave and chunk, served from L2), test beam against bound, and __ballot the
+// survivors; only those (a handful per wave) get the per-ray test of k_search.  Every primitive
+// is still looked at by every wave -- there is no hierarchy over the primitives -- but the work per
+// (ray, primitive) pair drops from 3.6 VALU instructions to ~0.05.
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int KIND>
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *__restrict__ L1,
+                                                                  const float4 *__restrict__ L2, int n_padded,
+                                                                  const float4 *__restrict__ ray32, uint32_t n_rays,
+                                                                  const uint32_t *__restrict__ active_rid,
+                                                                  const uint32_t *__restrict__ n_active,
+                                                                  uint32_t *__restrict__ cand,
+                                                                  uint32_t *__restrict__ cand_cnt,
+                                                                  unsigned long long *__restrict__ counters) {
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
+    const uint32_t total = active_rid ? *n_active : n_rays;
+    if (blockIdx.x * RAYS_PER_TILE >= total) return;
+    float rx[RAYS_PER_THREAD], ry[RAYS_PER_THREAD], rz[RAYS_PER_THREAD], rw[RAYS_PER_THREAD];
+    uint32_t cnt[RAYS_PER_THREAD], rid[RAYS_PER_THREAD];
+    float sx = 0.f, sy = 0.f, sz = 0.f, nact = 0.f, msq_max = 0.f;
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_THREAD; r++) {
+        const uint32_t slot = base + r * SEARCH_THREADS;
+        const bool live = slot < total;
+        rid[r] = active_rid ? (live ? active_rid[slot] : 0u) : slot;
+        float4 q = live ? ray32[rid[r]] : nan4();
+        rx[r] = q.x; ry[r] = q.y; rz[r] = q.z; rw[r] = q.w; cnt[r] = 0;
+        if (q.x == q.x) {
+            sx += q.x; sy += q.y; nact += 1.f;
+            if (KIND == 1) sz += q.z; else msq_max = fmaxf(msq_max, q.z);
+        }
+    }
+    // ---- the wave's beam
+    sx = wave_sum_f(sx); sy = wave_sum_f(sy); nact = wave_sum_f(nact);
+    float ax, ay, az = 0.f, cosb = -1.f, sinb = 0.f, rho = 0.f;
+    bool everything = false; // beam degenerate: test every primitive per ray
+    if (KIND == 1) {
+        sz = wave_sum_f(sz);
+        float len2 = sx * sx + sy * sy + sz * sz;
+        float inv = 1.0f / sqrtf(fmaxf(len2, 1e-30f));
+        ax = sx * inv; ay = sy * inv; az = sz * inv;
+        float lo = 1.f;
+#pragma unroll
+        for (int r = 0; r < RAYS_PER_THREAD; r++)
+            if (rx[r] == rx[r]) lo = fminf(lo, __builtin_fmaf(rz[r], az, __builtin_fmaf(ry[r], ay, rx[r] * ax)));
+        cosb = fmaxf(wave_min_f(lo) - 2e-6f, -1.f);
+        sinb = sqrtf(fmaxf(0.f, 1.f - cosb * cosb));
+        everything = !(len2 > 1e-12f);
+    } else {
+        float inv = 1.0f / fmaxf(nact, 1.f);
+        ax = sx * inv; ay = sy * inv;
+        float far = 0.f;
+#pragma unroll
+        for (int r = 0; r < RAYS_PER_THREAD; r++)
+            if (rx[r] == rx[r]) {
+                float du = rx[r] - ax, dv = ry[r] - ay;
+                far = fmaxf(far, __builtin_fmaf(du, du, dv * dv));
+            }
+        msq_max = wave_max_f(msq_max);
+        rho = sqrtf(wave_max_f(far));
+        rho = rho * (1.f + 1e-5f) + 4e-6f * (fabsf(ax) + fabsf(ay) + rho);
+        everything = !(rho == rho) || !(rho < 3.0e38f);
+    }
+    uint32_t n_surv = 0;
+    if (nact > 0.f) {
+        const int n_chunks = n_padded / 64;
+        for (int chunk = 0; chunk < n_chunks; chunk++) {
+            const float4 p = L1[(size_t)chunk * 64 + lane];
+            bool surv;
+            if (KIND == 1) {
+                const float ct = -p.w; // cosine threshold of the primitive's cone (2 = never, -2 = always)
+                const float ca = __builtin_fmaf(az, p.z, __builtin_fmaf(ay, p.y, ax * p.x));
+                const float ctc = fminf(fmaxf(ct, -1.f), 1.f);
+                const float st = sqrtf(fmaxf(0.f, 1.f - ctc * ctc));
+                const float rhs = __builtin_fmaf(ctc, cosb, -st * sinb) - 4e-6f; // cos(theta + beta)
+                surv = (ct < 1.5f) && (ct <= -1.5f || ctc < -cosb || ca >= rhs || everything);
+            } else {
+                const float du = p.x - ax, dv = p.y - ay;
+                const float d2 = __builtin_fmaf(du, du, dv * dv);
+                const float R = sqrtf(fmaxf(p.z, 0.f)) + rho;
+                surv = (p.z >= 0.f) && (d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq_max) || everything);
+            }
+            unsigned long long mask = __ballot(surv);
+            n_surv += (uint32_t)__popcll(mask);
+            while (mask) {
+                const int i = __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                float4 q;
+                q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
+                const uint32_t prim = (uint32_t)(chunk * 64 + i);
+#pragma unroll
+                for (int r = 0; r < RAYS_PER_THREAD; r++)
+                    if (pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f))
+                        append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RAYS_PER_THREAD; r++)
+        if (base + r * SEARCH_THREADS < total) cand_cnt[rid[r]] = cnt[r];
+    if (lane == 0 && n_surv)
+        atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
 }
 
 // ---- fp64 closest hit over a ray's candidates (or over everything) -----------------------------------
@@ -707,6 +925,7 @@ struct rt355_scene {
     std::vector<hipEvent_t> ev_search; // begin/end pairs
     int search_launches = 0;
     double search_ms = 0;
+    std::vector<double> launch_ms;
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
     uint64_t pending_primary = 0, pending_pairs_static = 0;
@@ -820,7 +1039,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.rec_pre, w.ray32, w.cand_cnt, w.cand,
-                  w.tile_count, w.active_rid};
+                  w.tile_count, w.active_rid, w.bin_hist};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
     w = Work{};
@@ -869,6 +1088,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
     HIP_TRY(hipMalloc((void **)&w.cand, (size_t)CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.active_rid, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.bin_hist, (RT_BINS + 2) * sizeof(uint32_t)));
     sc->work_rays = n_rays;
     return RT355_OK;
 }
@@ -897,14 +1117,15 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     int y0 = opts->row_begin, y1 = opts->row_end;
     if (y0 == 0 && y1 == 0) y1 = opts->height;
     if (y0 < 0 || y1 > opts->height || y0 >= y1) return fail(RT355_ERR_ARG, "row slab out of range");
-    if (opts->mode != RT355_MODE_FAST && opts->mode != RT355_MODE_BRUTE) return fail(RT355_ERR_ARG, "unknown mode");
+    if (opts->mode != RT355_MODE_FAST && opts->mode != RT355_MODE_BRUTE && opts->mode != RT355_MODE_PACKET)
+        return fail(RT355_ERR_ARG, "unknown mode");
     HIP_TRY(hipSetDevice(sc->device));
     if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     hipStream_t st = (hipStream_t)hip_stream;
 
     Frame f;
     f.width = opts->width; f.height = opts->height; f.row_begin = y0; f.rows = y1 - y0;
-    f.tiles_x = (f.width + TILE_W - 1) / TILE_W; f.tiles_y = (f.rows + TILE_W - 1) / TILE_W;
+    f.tiles_x = (f.width + TILE_W - 1) / TILE_W; f.tiles_y = (f.rows + TILE_H - 1) / TILE_H;
     uint64_t n_rays64 = (uint64_t)f.tiles_x * f.tiles_y * RAYS_PER_TILE;
     if (n_rays64 > 0x7fffffffull) return fail(RT355_ERR_ARG, "slab too large: split it into fewer rows per call");
     f.n_rays = (uint32_t)n_rays64;
@@ -935,7 +1156,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
 
     // bundle 0 = camera rays (common origin: the eye); bundle 1+k = shadow rays of light k (common
     // origin: the light position, or common direction for a directional light)
-    const bool can_search = (opts->mode == RT355_MODE_FAST) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
+    const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
     std::vector<Bundle> bundles(2 + nl);
     std::vector<d3> ray_dir(2 + nl);
     for (auto &b : bundles) memset(&b, 0, sizeof b);
@@ -976,14 +1197,30 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         else
             hipLaunchKernelGGL(k_bundle_direction, dim3(setup_blocks), dim3(256), 0, st, sc->view, b, ray_dir[bi], sc->n_padded, sc->L1, sc->L2);
         const uint32_t *list = nullptr, *total = nullptr;
-        if (!is_eye) { // shadow bundles are sparse: compact their active rays first
+        if (!is_eye && opts->mode == RT355_MODE_PACKET) { // order the active rays by direction
+            const float ext = (float)(2.0 * (sc->extent + sc->rmax) + 1.0);
+            HIP_TRY(hipMemsetAsync(sc->work.bin_hist, 0, (RT_BINS + 2) * sizeof(uint32_t), st));
+            if (b.kind == 1) hipLaunchKernelGGL(k_bin_count<1>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist);
+            else hipLaunchKernelGGL(k_bin_count<2>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, sc->work.bin_hist, (int)RT_BINS);
+            // the total lives past the last bin; copy it where the scatter's atomics do not reach
+            HIP_TRY(hipMemcpyAsync(sc->work.bin_hist + RT_BINS + 1, sc->work.bin_hist + RT_BINS, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            if (b.kind == 1) hipLaunchKernelGGL(k_bin_scatter<1>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist, sc->work.active_rid);
+            else hipLaunchKernelGGL(k_bin_scatter<2>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist, sc->work.active_rid);
+            list = sc->work.active_rid; total = sc->work.bin_hist + RT_BINS + 1;
+        } else if (!is_eye) { // shadow bundles are sparse: compact their active rays first
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count);
             hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, sc->work.tile_count, (int)n_tiles);
             hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count, sc->work.active_rid);
             list = sc->work.active_rid; total = sc->work.tile_count + n_tiles;
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
-        if (b.kind == 1)
+        if (opts->mode == RT355_MODE_PACKET) {
+            if (b.kind == 1)
+                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+            else
+                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+        } else if (b.kind == 1)
             hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
         else
             hipLaunchKernelGGL(k_search<2>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
@@ -1026,10 +1263,12 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
     sc->search_ms = 0;
+    sc->launch_ms.assign(sc->search_launches, 0.0);
     for (int i = 0; i < sc->search_launches; i++) {
         float m = 0;
         HIP_TRY(hipEventElapsedTime(&m, sc->ev_search[2 * i], sc->ev_search[2 * i + 1]));
         sc->search_ms += m;
+        sc->launch_ms[i] = m;
     }
     if (sc->pending_stats) {
         rt355_stats *s = sc->pending_stats;
@@ -1039,6 +1278,7 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->overflow_rays = ctr[2];
         s->pair_tests = (sc->pending_primary + ctr[0]) * (uint64_t)sc->pending_nprims;
         s->ms_device = ms;
+        s->packet_survivors = ctr[3];
     }
     return RT355_OK;
 }
@@ -1047,6 +1287,12 @@ extern "C" int rt355_scene_search_kernel_ms(rt355_scene *sc, double *ms_sum, int
     if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
     *ms_sum = sc->search_ms;
     *launches = sc->search_launches;
+    return RT355_OK;
+}
+
+extern "C" int rt355_scene_search_launch_ms(rt355_scene *sc, int32_t index, double *ms) {
+    if (!sc || !ms || index < 0 || index >= (int32_t)sc->launch_ms.size()) return fail(RT355_ERR_ARG, "bad launch index");
+    *ms = sc->launch_ms[index];
     return RT355_OK;
 }
 

@@ -39,7 +39,7 @@ def _compare(got, want, exact=True):
         assert int(np.abs(diff).max()) <= 1
 
 
-@pytest.mark.parametrize("mode", [B.MODE_FAST, B.MODE_BRUTE])
+@pytest.mark.parametrize("mode", [B.MODE_FAST, B.MODE_BRUTE, B.MODE_PACKET])
 @pytest.mark.parametrize("name", S.SMALL_CASES)
 def test_small_cases_vs_golden(api, golden_dir, name, mode):
     gold = np.load(os.path.join(golden_dir, f"frame_{name}.npy"))
@@ -95,11 +95,15 @@ def test_mid_size_scenes_vs_checker(api, oracle):
         r = api.Renderer(sc)
         got, st = r.render(cam, sh, w, h)
         brute, _ = r.render(cam, sh, w, h, mode=B.MODE_BRUTE)
+        packet, pst = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
         r.close()
         _compare(got, want)
         _compare(brute, want)
+        _compare(packet, want)
         assert st["shadow_rays"] == wst["shadow_rays"]
         assert st["overflow_rays"] == 0
+        # the packet search proposes exactly the candidates of the all-pairs search
+        assert pst["exact_tests"] == st["exact_tests"]
 
 
 def test_orbit_cameras_mesh(api, oracle):
@@ -209,7 +213,7 @@ def _random_case(seed):
         sc.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
     if rng.uniform() < 0.5:
         sc.add_plane((0, 40, 0), (0, -1, 0), (-1, 0, 0), (200, 200, 200))
-    n_sph = int(rng.uniform(20, 150))
+    n_sph = int(rng.uniform(70, 200))
     for _ in range(n_sph):
         c = (rng.uniform(-25, 25), rng.uniform(-5, 35), rng.uniform(-9, 15))
         sc.add_sphere(c, rng.uniform(0.2, 3.5), (int(rng.uniform(30, 255)), int(rng.uniform(30, 255)), int(rng.uniform(30, 255))))
@@ -242,6 +246,9 @@ def test_random_scenes_search_is_conservative(api, oracle, seed):
     want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
     r = api.Renderer(sc)
     got, st = r.render(cam, sh, w, h)
+    packet, pst = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
     r.close()
     _compare(got, want)
+    _compare(packet, want)
     assert st["shadow_rays"] == wst["shadow_rays"]
+    assert pst["exact_tests"] == st["exact_tests"]
