@@ -79,7 +79,8 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     unsigned long long *counters; // 0 shadow rays, 1 candidates evaluated, 2 overflow rays
     uint32_t *tile_count; // [tiles + 1] active rays per tile, then exclusive offsets; last = total
     uint32_t *active_rid; // [n] rids of the current bundle's active rays, tile-major order kept
-    uint32_t *bin_hist;   // [RT_BINS + 1] packet search: rays per direction bin, then offsets
+    uint32_t *bin_hist;   // [RT_BINS + 2] packet search: rays per direction bin, then offsets
+    uint32_t *bin_id;     // [n] packet search: direction bin of each ray, 0xffffffff = inactive
 };
 
 // Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
@@ -183,6 +184,8 @@ struct Bundle {
     d3 o;         // kind 1: the origin
     d3 e1, e2;    // kind 2: basis of the projection plane
     double rmaxp; // kind 2: upper bound of (bounding radius + per-primitive rounding bound)
+    int binned;   // packet search: the rays of this bundle are also counted into direction bins
+    float plane_extent; // kind 2: half-width of the binning grid on the projection plane
 };
 #define RT_EPS22 2.384185791015625e-07 /* 2^-22 */
 
@@ -345,26 +348,25 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 
 // sort on a 256x256 grid over the sphere of directions (octahedral map) or over the projection
 // plane, cells numbered in Morton order so that consecutive cells are neighbours.  Order inside a
 // cell is whatever the atomics give; candidates are per ray, so frames do not depend on it.
-#define RT_BINS 65536
-// index of cell (x, y) of a 256x256 grid along the Hilbert curve: consecutive indices are always
+#define RT_BINS 16384 /* 128 x 128 cells */
+// index of cell (x, y) of a 128x128 grid along the Hilbert curve: consecutive indices are always
 // neighbouring cells, so any run of consecutive rays covers one connected patch of directions
-__device__ __forceinline__ uint32_t hilbert8(uint32_t x, uint32_t y) {
+__device__ __forceinline__ uint32_t hilbert7(uint32_t x, uint32_t y) {
     uint32_t d = 0;
 #pragma unroll
-    for (uint32_t s = 128; s > 0; s >>= 1) {
+    for (uint32_t s = 64; s > 0; s >>= 1) {
         uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
         d += s * s * ((3u * rx) ^ ry);
         if (ry == 0) {
-            if (rx == 1) { x = 255u - x; y = 255u - y; }
+            if (rx == 1) { x = 127u - x; y = 127u - y; }
             uint32_t tmp = x; x = y; y = tmp;
         }
     }
     return d;
 }
-template <int KIND>
-__device__ __forceinline__ uint32_t ray_bin(const float4 &q, float plane_extent) {
+__device__ __forceinline__ uint32_t ray_bin(int kind, const float4 &q, float plane_extent) {
     float u, v;
-    if (KIND == 1) { // octahedral map of the unit direction
+    if (kind == 1) { // octahedral map of the unit direction
         float inv = 1.0f / (fabsf(q.x) + fabsf(q.y) + fabsf(q.z));
         float px = q.x * inv, py = q.y * inv;
         if (q.z < 0.f) {
@@ -376,14 +378,25 @@ __device__ __forceinline__ uint32_t ray_bin(const float4 &q, float plane_extent)
     } else {         // grid over the projection plane; far-away origins share the border cells
         u = q.x / plane_extent * 0.5f + 0.5f; v = q.y / plane_extent * 0.5f + 0.5f;
     }
-    int ix = (int)fminf(fmaxf(u * 256.f, 0.f), 255.f), iy = (int)fminf(fmaxf(v * 256.f, 0.f), 255.f);
-    return hilbert8((uint32_t)ix, (uint32_t)iy);
+    int ix = (int)fminf(fmaxf(u * 128.f, 0.f), 127.f), iy = (int)fminf(fmaxf(v * 128.f, 0.f), 127.f);
+    return hilbert7((uint32_t)ix, (uint32_t)iy);
 }
-// Rays of a wave mostly fall into a few cells, so the wave adds ONE atomic per distinct cell:
-// repeatedly take the cell of the first pending lane, ballot the lanes that share it, let the
-// leader add their count, and hand every such lane its rank.  Returns the value of the counter
-// before this wave's add plus the lane's rank (only meaningful for active lanes).
-__device__ __forceinline__ uint32_t wave_bin_add(uint32_t *__restrict__ counters, uint32_t bin, bool active) {
+// Rays of a wave mostly fall into a few cells, so the wave issues ONE atomic per distinct cell:
+// repeatedly take the cell of the first pending lane, ballot the lanes that share it, and let the
+// leader add their count.  Must be called by all lanes of the wave (inactive lanes pass false).
+__device__ __forceinline__ void wave_bin_count(uint32_t *__restrict__ hist, uint32_t bin, bool active) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long pending = __ballot(active);
+    while (pending) {
+        const int leader = __builtin_ctzll(pending);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(active && bin == b) & pending;
+        if ((int)lane == leader) atomicAdd(&hist[b], (uint32_t)__popcll(same)); // result unused: no-return atomic
+        pending &= ~same;
+    }
+}
+// Same walk, but every lane learns its slot: counter value before the wave's add + rank in the cell.
+__device__ __forceinline__ uint32_t wave_bin_slot(uint32_t *__restrict__ offsets, uint32_t bin, bool active) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t result = 0;
     unsigned long long pending = __ballot(active);
@@ -392,30 +405,53 @@ __device__ __forceinline__ uint32_t wave_bin_add(uint32_t *__restrict__ counters
         const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
         const unsigned long long same = __ballot(active && bin == b) & pending;
         uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&counters[b], (uint32_t)__popcll(same));
+        if ((int)lane == leader) base = atomicAdd(&offsets[b], (uint32_t)__popcll(same));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
         if ((same >> lane) & 1ull) result = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
         pending &= ~same;
     }
     return result;
 }
-template <int KIND>
-__global__ __launch_bounds__(256) void k_bin_count(const float4 *__restrict__ ray32, uint32_t n_rays,
-                                                   float plane_extent, uint32_t *__restrict__ hist) {
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // n_rays is a multiple of the block size
-    float4 q = ray32[rid];
-    bool active = q.x == q.x;
-    wave_bin_add(hist, active ? ray_bin<KIND>(q, plane_extent) : 0u, active);
-}
-template <int KIND>
-__global__ __launch_bounds__(256) void k_bin_scatter(const float4 *__restrict__ ray32, uint32_t n_rays,
-                                                     float plane_extent, uint32_t *__restrict__ offsets,
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id, uint32_t *__restrict__ offsets,
                                                      uint32_t *__restrict__ active_rid) {
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    float4 q = ray32[rid];
-    bool active = q.x == q.x;
-    uint32_t pos = wave_bin_add(offsets, active ? ray_bin<KIND>(q, plane_extent) : 0u, active);
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // the ray count is a multiple of the block size
+    uint32_t bin = bin_id[rid];
+    bool active = bin != 0xffffffffu;
+    uint32_t pos = wave_bin_slot(offsets, bin, active);
     if (active) active_rid[pos] = rid;
+}
+
+// Offsets of the direction bins, with every run of 16 consecutive bins (a 4x4 patch of cells on
+// the Hilbert curve) padded to a multiple of 256 rays, so that no wave of the packet search
+// mixes rays of different patches: a wave's beam is never wider than one patch, whatever the ray
+// density.  One workgroup; thread c owns patch c.  hist[RT_BINS + 1] receives the padded total.
+#define RT_PATCH 16
+__global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist) {
+    __shared__ uint32_t part[1024];
+    const int c = threadIdx.x;
+    uint4 v[RT_PATCH / 4];
+    const uint4 *src = (const uint4 *)(hist + (size_t)c * RT_PATCH);
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < RT_PATCH / 4; i++) { v[i] = src[i]; sum += v[i].x + v[i].y + v[i].z + v[i].w; }
+    const uint32_t padded = (sum + 255u) & ~255u;
+    part[c] = padded;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t x = (c >= off) ? part[c - off] : 0u;
+        __syncthreads();
+        part[c] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[c] - padded;
+    uint4 *dst = (uint4 *)(hist + (size_t)c * RT_PATCH);
+#pragma unroll
+    for (int i = 0; i < RT_PATCH / 4; i++) {
+        uint4 o;
+        o.x = run; run += v[i].x; o.y = run; run += v[i].y; o.z = run; run += v[i].z; o.w = run; run += v[i].w;
+        dst[i] = o;
+    }
+    if (c == 1023) hist[RT_BINS + 1] = part[1023];
 }
 
 // ---- the all-pairs candidate search ------------------------------------------------------------------
@@ -577,18 +613,24 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
                                                                   uint32_t *__restrict__ cand_cnt,
                                                                   unsigned long long *__restrict__ counters) {
     const uint32_t t = threadIdx.x, lane = t & 63u;
-    const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
     const uint32_t total = active_rid ? *n_active : n_rays;
     if (blockIdx.x * RAYS_PER_TILE >= total) return;
+    // With a sorted list a wave takes 64*RAYS_PER_THREAD CONSECUTIVE entries (rays that point the
+    // same way); without one it keeps the screen tiling of rid_to_xy.
+    const uint32_t base = active_rid ? blockIdx.x * RAYS_PER_TILE + (t >> 6) * (64 * RAYS_PER_THREAD) + lane
+                                     : blockIdx.x * RAYS_PER_TILE + t;
+    const uint32_t stride = active_rid ? 64u : (uint32_t)SEARCH_THREADS;
     float rx[RAYS_PER_THREAD], ry[RAYS_PER_THREAD], rz[RAYS_PER_THREAD], rw[RAYS_PER_THREAD];
     uint32_t cnt[RAYS_PER_THREAD], rid[RAYS_PER_THREAD];
+    bool live[RAYS_PER_THREAD];
     float sx = 0.f, sy = 0.f, sz = 0.f, nact = 0.f, msq_max = 0.f;
 #pragma unroll
     for (int r = 0; r < RAYS_PER_THREAD; r++) {
-        const uint32_t slot = base + r * SEARCH_THREADS;
-        const bool live = slot < total;
-        rid[r] = active_rid ? (live ? active_rid[slot] : 0u) : slot;
-        float4 q = live ? ray32[rid[r]] : nan4();
+        const uint32_t slot = base + r * stride;
+        live[r] = slot < total;
+        rid[r] = active_rid ? (live[r] ? active_rid[slot] : 0xffffffffu) : slot;
+        if (rid[r] == 0xffffffffu) live[r] = false;
+        float4 q = live[r] ? ray32[rid[r]] : nan4();
         rx[r] = q.x; ry[r] = q.y; rz[r] = q.z; rw[r] = q.w; cnt[r] = 0;
         if (q.x == q.x) {
             sx += q.x; sy += q.y; nact += 1.f;
@@ -628,43 +670,58 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
     }
     uint32_t n_surv = 0;
     if (nact > 0.f) {
-        const int n_chunks = n_padded / 64;
-        for (int chunk = 0; chunk < n_chunks; chunk++) {
-            const float4 p = L1[(size_t)chunk * 64 + lane];
-            bool surv;
-            if (KIND == 1) {
-                const float ct = -p.w; // cosine threshold of the primitive's cone (2 = never, -2 = always)
-                const float ca = __builtin_fmaf(az, p.z, __builtin_fmaf(ay, p.y, ax * p.x));
-                const float ctc = fminf(fmaxf(ct, -1.f), 1.f);
-                const float st = sqrtf(fmaxf(0.f, 1.f - ctc * ctc));
-                const float rhs = __builtin_fmaf(ctc, cosb, -st * sinb) - 4e-6f; // cos(theta + beta)
-                surv = (ct < 1.5f) && (ct <= -1.5f || ctc < -cosb || ca >= rhs || everything);
-            } else {
-                const float du = p.x - ax, dv = p.y - ay;
-                const float d2 = __builtin_fmaf(du, du, dv * dv);
-                const float R = sqrtf(fmaxf(p.z, 0.f)) + rho;
-                surv = (p.z >= 0.f) && (d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq_max) || everything);
-            }
-            unsigned long long mask = __ballot(surv);
-            n_surv += (uint32_t)__popcll(mask);
-            while (mask) {
-                const int i = __builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                float4 q;
-                q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
-                const uint32_t prim = (uint32_t)(chunk * 64 + i);
+        const int n_chunks = n_padded / 64; // a multiple of 8
+        // four table reads are kept in flight per wave: the loop is bound by L2 latency otherwise
+        for (int c0 = 0; c0 < n_chunks; c0 += 4) {
+            float4 pc[4];
 #pragma unroll
-                for (int r = 0; r < RAYS_PER_THREAD; r++)
-                    if (pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f))
-                        append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+            for (int u = 0; u < 4; u++) pc[u] = L1[(size_t)(c0 + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float4 p = pc[u];
+                const int chunk = c0 + u;
+                bool surv;
+                if (KIND == 1) {
+                    const float ct = -p.w; // cosine threshold of the primitive's cone (2 = never, -2 = always)
+                    const float ca = __builtin_fmaf(az, p.z, __builtin_fmaf(ay, p.y, ax * p.x));
+                    const float ctc = fminf(fmaxf(ct, -1.f), 1.f);
+                    const float st = sqrtf(fmaxf(0.f, 1.f - ctc * ctc));
+                    const float rhs = __builtin_fmaf(ctc, cosb, -st * sinb) - 4e-6f; // cos(theta + beta)
+                    surv = (ct < 1.5f) && (ct <= -1.5f || ctc < -cosb || ca >= rhs || everything);
+                } else {
+                    const float du = p.x - ax, dv = p.y - ay;
+                    const float d2 = __builtin_fmaf(du, du, dv * dv);
+                    const float R = sqrtf(fmaxf(p.z, 0.f)) + rho;
+                    surv = (p.z >= 0.f) && (d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq_max) || everything);
+                }
+                unsigned long long mask = __ballot(surv);
+                n_surv += (uint32_t)__popcll(mask);
+                while (mask) {
+                    const int i = __builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    float4 q;
+                    q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
+                    const uint32_t prim = (uint32_t)(chunk * 64 + i);
+#pragma unroll
+                    for (int r = 0; r < RAYS_PER_THREAD; r++)
+                        if (pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f))
+                            append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                }
             }
         }
     }
 #pragma unroll
     for (int r = 0; r < RAYS_PER_THREAD; r++)
-        if (base + r * SEARCH_THREADS < total) cand_cnt[rid[r]] = cnt[r];
-    if (lane == 0 && n_surv)
+        if (live[r]) cand_cnt[rid[r]] = cnt[r];
+    if (lane == 0 && n_surv) {
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
+#ifdef RT355_DEBUG_SURVIVORS
+        atomicMax(&counters[4], (unsigned long long)n_surv);
+        if (n_surv > 256) atomicAdd(&counters[5], 1ull);
+        if (n_surv > 1024) atomicAdd(&counters[6], 1ull);
+        if (n_surv > 4096) atomicAdd(&counters[7], 1ull);
+#endif
+    }
 }
 
 // ---- fp64 closest hit over a ray's candidates (or over everything) -----------------------------------
@@ -706,7 +763,7 @@ __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, 
 // Colour of light k before CalcShadow (shader.h:75-89) and the shadow ray it needs.
 __device__ __forceinline__ uint32_t light_prepare(const ShaderView &sh, int k, const Bundle &bd, d3 pe, d3 ph, d3 nh,
                                               d3 npe, uint32_t cm0, uint32_t cm1, bool no_border, uint32_t rid,
-                                              const Work &w) {
+                                              const Work &w, uint32_t &bin) {
     const DLight &L = sh.lights[k];
     d3 nhl = light_nhl(L, ph);
     uint32_t clr = calc_diffuse(L, cm0, cm1, nh, nhl);
@@ -714,7 +771,11 @@ __device__ __forceinline__ uint32_t light_prepare(const ShaderView &sh, int k, c
     if (!no_border) clr = calc_border(sh, clr, pe, ph, nh);
     bool needs = !(dot(nh, vmul(nhl, -1)) <= 0); // shader.h:396
     w.rec_pre[rid] = clr | (needs ? (1u << 24) : 0u);
-    if (bd.kind) w.ray32[rid] = needs ? bundle_ray(bd, ph, nhl) : nan4();
+    if (bd.kind) {
+        float4 q = needs ? bundle_ray(bd, ph, nhl) : nan4();
+        w.ray32[rid] = q;
+        if (bd.binned && needs) bin = ray_bin(bd.kind, q, bd.plane_extent);
+    }
     return needs ? 1u : 0u;
 }
 
@@ -722,7 +783,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
                                                          int brute, Bundle next,
                                                          unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_shadow = 0, n_eval = 0, n_over = 0;
+    uint32_t n_shadow = 0, n_eval = 0, n_over = 0, bin = 0xffffffffu;
     do {
     if (rid >= f.n_rays) break;
     int x, y;
@@ -780,8 +841,12 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_cm0[rid] = cm0 | (no_border ? (1u << 24) : 0u);
     w.rec_cm1[rid] = cm1;
     w.rec_sum[rid] = 0u;
-    n_shadow = light_prepare(sh, 0, next, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w);
+    n_shadow = light_prepare(sh, 0, next, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w, bin);
     } while (0);
+    if (next.binned) { // all lanes of the wave arrive here
+        if (rid < f.n_rays) w.bin_id[rid] = bin;
+        wave_bin_count(w.bin_hist, bin, bin != 0xffffffffu);
+    }
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
@@ -793,7 +858,7 @@ __global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView s
                                                        int k, int brute, Bundle next,
                                                        unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_shadow = 0, n_eval = 0, n_over = 0;
+    uint32_t n_shadow = 0, n_eval = 0, n_over = 0, bin = 0xffffffffu;
     do {
     if (rid >= f.n_rays) break;
     int obj = w.rec_obj[rid];
@@ -831,8 +896,12 @@ __global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView s
     d3 npe = D3(w.rec_d[6 * n + rid], w.rec_d[7 * n + rid], w.rec_d[8 * n + rid]);
     uint32_t cm0 = w.rec_cm0[rid];
     n_shadow = light_prepare(sh, k + 1, next, ld3(cam.p_eye), ph, nh, npe, cm0 & 0xffffffu,
-                             w.rec_cm1[rid], (cm0 >> 24) & 1u, rid, w);
+                             w.rec_cm1[rid], (cm0 >> 24) & 1u, rid, w, bin);
     } while (0);
+    if (next.binned) { // all lanes of the wave arrive here
+        if (rid < f.n_rays) w.bin_id[rid] = bin;
+        wave_bin_count(w.bin_hist, bin, bin != 0xffffffffu);
+    }
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
@@ -1039,7 +1108,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.rec_pre, w.ray32, w.cand_cnt, w.cand,
-                  w.tile_count, w.active_rid, w.bin_hist};
+                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
     w = Work{};
@@ -1087,8 +1156,9 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, (size_t)CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.active_rid, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.active_rid, (n + RT_BINS / RT_PATCH * 256) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_hist, (RT_BINS + 2) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.bin_id, n * sizeof(uint32_t)));
     sc->work_rays = n_rays;
     return RT355_OK;
 }
@@ -1182,6 +1252,13 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         }
     }
 
+    if (opts->mode == RT355_MODE_PACKET)
+        for (int k = 0; k < nl; k++)
+            if (bundles[1 + k].kind) {
+                bundles[1 + k].binned = 1;
+                bundles[1 + k].plane_extent = (float)(2.0 * (sc->extent + sc->rmax) + 1.0);
+            }
+
     HIP_TRY(hipEventRecord(sc->ev_begin, st));
     HIP_TRY(hipMemsetAsync(sc->work.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
     const unsigned per_ray_blocks = (f.n_rays + 255) / 256;
@@ -1197,16 +1274,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         else
             hipLaunchKernelGGL(k_bundle_direction, dim3(setup_blocks), dim3(256), 0, st, sc->view, b, ray_dir[bi], sc->n_padded, sc->L1, sc->L2);
         const uint32_t *list = nullptr, *total = nullptr;
-        if (!is_eye && opts->mode == RT355_MODE_PACKET) { // order the active rays by direction
-            const float ext = (float)(2.0 * (sc->extent + sc->rmax) + 1.0);
-            HIP_TRY(hipMemsetAsync(sc->work.bin_hist, 0, (RT_BINS + 2) * sizeof(uint32_t), st));
-            if (b.kind == 1) hipLaunchKernelGGL(k_bin_count<1>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist);
-            else hipLaunchKernelGGL(k_bin_count<2>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist);
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, sc->work.bin_hist, (int)RT_BINS);
-            // the total lives past the last bin; copy it where the scatter's atomics do not reach
-            HIP_TRY(hipMemcpyAsync(sc->work.bin_hist + RT_BINS + 1, sc->work.bin_hist + RT_BINS, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-            if (b.kind == 1) hipLaunchKernelGGL(k_bin_scatter<1>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist, sc->work.active_rid);
-            else hipLaunchKernelGGL(k_bin_scatter<2>, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.ray32, f.n_rays, ext, sc->work.bin_hist, sc->work.active_rid);
+        if (b.binned) { // the producer of the rays counted them into direction bins: order them
+            hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, sc->work.bin_hist);
+            // padding slots of the sorted list stay 0xffffffff = no ray
+            HIP_TRY(hipMemsetAsync(sc->work.active_rid, 0xff, ((size_t)f.n_rays + RT_BINS / RT_PATCH * 256) * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.bin_id, sc->work.bin_hist, sc->work.active_rid);
             list = sc->work.active_rid; total = sc->work.bin_hist + RT_BINS + 1;
         } else if (!is_eye) { // shadow bundles are sparse: compact their active rays first
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count);
@@ -1216,10 +1288,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
+            const unsigned n_blocks = is_eye ? n_tiles : n_tiles + (RT_BINS / RT_PATCH * 256 + RAYS_PER_TILE - 1) / RAYS_PER_TILE;
             if (b.kind == 1)
-                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
             else
-                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
         } else if (b.kind == 1)
             hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
         else
@@ -1232,10 +1305,16 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, sc->work.ray32);
         if ((rc = run_search(0))) return rc;
     }
+    auto clear_bins = [&](const Bundle &nb) -> int { // the next kernel counts its rays into the bins
+        if (nb.binned) HIP_TRY(hipMemsetAsync(sc->work.bin_hist, 0, (RT_BINS + 2) * sizeof(uint32_t), st));
+        return RT355_OK;
+    };
+    if ((rc = clear_bins(bundles[1]))) return rc;
     hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work,
                        bundles[0].kind ? 0 : 1, bundles[1], pix);
     for (int k = 0; k < nl; k++) {
         if (bundles[1 + k].kind && (rc = run_search(1 + k))) return rc;
+        if ((rc = clear_bins(bundles[2 + k]))) return rc;
         hipLaunchKernelGGL(k_light_resolve, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work, k,
                            bundles[1 + k].kind ? 0 : 1, bundles[2 + k], pix);
     }
@@ -1279,6 +1358,9 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->pair_tests = (sc->pending_primary + ctr[0]) * (uint64_t)sc->pending_nprims;
         s->ms_device = ms;
         s->packet_survivors = ctr[3];
+#ifdef RT355_DEBUG_SURVIVORS
+        fprintf(stderr, "[rt355] survivors: total %llu max/wave %llu waves>256 %llu >1024 %llu >4096 %llu\n", ctr[3], shards[4], shards[5], shards[6], shards[7]);
+#endif
     }
     return RT355_OK;
 }
