@@ -38,6 +38,10 @@
 #define TILE_W 32                       // tile width in pixels; one workgroup searches one tile
 #define TILE_H (8 * RAYS_PER_THREAD)    // tile height in pixels
 #define RAYS_PER_TILE (SEARCH_THREADS * RAYS_PER_THREAD)
+#ifndef PACKET_RAYS
+#define PACKET_RAYS 4 // rays per lane of the packet search: a multiple of RAYS_PER_THREAD
+#endif
+#define PACKET_BLOCK_RAYS (SEARCH_THREADS * PACKET_RAYS)
 #ifndef PRIM_TILE
 #define PRIM_TILE 512       // primitives staged in LDS per step (8 KiB, double buffered)
 #endif
@@ -81,6 +85,7 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *active_rid; // [n] rids of the current bundle's active rays, tile-major order kept
     uint32_t *bin_hist;   // [RT_BINS + 2] packet search: rays per direction bin, then offsets
     uint32_t *bin_id;     // [n] packet search: direction bin of each ray, 0xffffffff = inactive
+    uint32_t *bin_rank;   // [n] packet search: rank of the ray inside its bin
 };
 
 // Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
@@ -107,18 +112,21 @@ __device__ __forceinline__ float4 nan4() {
 // L2[3i..3i+2] = inward unit normals of the three planes through the origin and a triangle
 // edge; d can only hit the triangle if d . n >= -eps for all three.  Zero rows always pass.
 __global__ void k_bundle_origin(SceneView s, d3 O, int is_eye, int n_padded, float4 *__restrict__ L1,
-                                float4 *__restrict__ L2) {
+                                float4 *__restrict__ L2, float *__restrict__ L1s) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_padded) return;
     float4 never = make_float4(0.f, 0.f, 0.f, -2.f), always = make_float4(0.f, 0.f, 0.f, 2.f);
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 l1 = never, a = z4, b = z4, c = z4;
+    // L1s[i] = sine of the cone's (inflated) half angle, used by the packet search's beam test:
+    // 0 for "always", -inf for "never" (which turns cos(theta + beta) into +inf or NaN: no survivor)
+    float sin_t = -__builtin_inff();
     if (i < s.n_prims) {
         int obj = s.prim_obj[i], tri = s.prim_tri[i];
         d3 ctr; double rad; bool sphere_like = false;
         if (tri < 0) {
             const DObject &o = s.objects[obj];
-            if (o.type == RT_OBJ_PLANE) l1 = always;
+            if (o.type == RT_OBJ_PLANE) { l1 = always; sin_t = 0.f; }
             else { ctr = ld3(o.p); rad = fabs(o.radius); sphere_like = true; }
         } else {
             const DTriangle &t = s.tris[tri];
@@ -156,15 +164,17 @@ __global__ void k_bundle_origin(SceneView s, d3 O, int is_eye, int n_padded, flo
             d3 oc = vsub(ctr, O);
             double d2 = dot(oc, oc);
             if (d2 <= rad * rad * (1.0 + 1e-5) + 1e-300) {
-                l1 = always;
+                l1 = always; sin_t = 0.f;
             } else {
                 double dist = sqrt(d2), sn = rad / dist;
                 double thr = sqrt(1.0 - sn * sn) - 2e-6; // fp32 evaluation error of d.o is < 4e-7
                 l1 = make_float4((float)(oc.x / dist), (float)(oc.y / dist), (float)(oc.z / dist), (float)(-thr));
+                sin_t = (float)(sqrt(fmax(0.0, 1.0 - thr * thr)) * (1.0 + 1e-6));
             }
         }
     }
     L1[i] = l1;
+    L1s[i] = sin_t;
     L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
 }
 
@@ -172,8 +182,8 @@ __global__ void k_bundle_origin(SceneView s, d3 O, int is_eye, int n_padded, flo
 // runs along w = -direction.  With an orthonormal basis (e1, e2, w), "ray from ph hits sphere
 // (c, r)" needs the 2-D distance between the projections of ph and c to be <= r, and "hits
 // triangle" needs the projection of ph inside the projected triangle.
-//   L1[i] = (u_c, v_c, R2, 0): projected centre and inflated squared radius of primitive i's
-//           bounding circle; R2 = +inf "always" (planes), -inf "never" (culled, padding).
+//   L1[i] = (u_c, v_c, R2, R): projected centre, inflated squared radius and radius of primitive
+//           i's bounding circle; R2 = +inf "always" (planes), -inf "never" (culled, padding).
 //   L2[3i..3i+2] = (A, B, C, 0): inward unit edge functions A*u + B*v + C of the projected
 //           triangle, C already raised by the per-primitive rounding bound.  Zero rows pass.
 // A ray carries (u_p, v_p, m_sq, m_lin): its projected origin and the two bounds that cover the
@@ -194,7 +204,8 @@ __global__ void k_bundle_direction(SceneView s, Bundle bd, d3 w, int n_padded, f
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_padded) return;
     const float inf = __builtin_inff();
-    float4 never = make_float4(0.f, 0.f, -inf, 0.f), always = make_float4(0.f, 0.f, inf, 0.f);
+    // .w = the circle's radius for the packet search's beam test: NaN "never", +inf "always"
+    float4 never = make_float4(0.f, 0.f, -inf, __builtin_nanf("")), always = make_float4(0.f, 0.f, inf, inf);
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 l1 = never, a = z4, b = z4, c = z4;
     if (i < s.n_prims) {
@@ -238,7 +249,7 @@ __global__ void k_bundle_direction(SceneView s, Bundle bd, d3 w, int n_padded, f
             double uc = dot(ctr, bd.e1), vc = dot(ctr, bd.e2);
             double es = RT_EPS22 * (fabs(uc) + fabs(vc) + rad);
             double R = rad + es;
-            l1 = make_float4((float)uc, (float)vc, (float)(R * R * (1.0 + 1e-6)), 0.f);
+            l1 = make_float4((float)uc, (float)vc, (float)(R * R * (1.0 + 1e-6)), (float)(R * (1.0 + 1e-6)));
         }
     }
     L1[i] = l1;
@@ -381,44 +392,39 @@ __device__ __forceinline__ uint32_t ray_bin(int kind, const float4 &q, float pla
     int ix = (int)fminf(fmaxf(u * 128.f, 0.f), 127.f), iy = (int)fminf(fmaxf(v * 128.f, 0.f), 127.f);
     return hilbert7((uint32_t)ix, (uint32_t)iy);
 }
-// Rays of a wave mostly fall into a few cells, so the wave issues ONE atomic per distinct cell:
-// repeatedly take the cell of the first pending lane, ballot the lanes that share it, and let the
-// leader add their count.  Must be called by all lanes of the wave (inactive lanes pass false).
-__device__ __forceinline__ void wave_bin_count(uint32_t *__restrict__ hist, uint32_t bin, bool active) {
+// Rays of a wave mostly fall into a few cells.  The wave first groups its lanes by cell with
+// ballots only (no memory traffic), then the first lane of every group adds the group's size to
+// the cell counter in ONE atomic instruction for the whole wave, and each lane's rank inside its
+// cell is the returned counter value plus its rank inside the group.  Must be called by all
+// lanes of the wave (inactive lanes pass false).  Returns the rank of the lane's ray in its cell.
+__device__ __forceinline__ uint32_t wave_bin_rank(uint32_t *__restrict__ hist, uint32_t bin, bool active) {
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t leader_lane = lane, rank = 0, count = 0;
     unsigned long long pending = __ballot(active);
     while (pending) {
         const int leader = __builtin_ctzll(pending);
         const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
         const unsigned long long same = __ballot(active && bin == b) & pending;
-        if ((int)lane == leader) atomicAdd(&hist[b], (uint32_t)__popcll(same)); // result unused: no-return atomic
+        if ((same >> lane) & 1ull) {
+            leader_lane = (uint32_t)leader;
+            rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            count = (uint32_t)__popcll(same);
+        }
         pending &= ~same;
     }
+    uint32_t base = 0;
+    if (active && lane == leader_lane) base = atomicAdd(&hist[bin], count);
+    base = (uint32_t)__shfl((int)base, (int)leader_lane, 64);
+    return base + rank;
 }
-// Same walk, but every lane learns its slot: counter value before the wave's add + rank in the cell.
-__device__ __forceinline__ uint32_t wave_bin_slot(uint32_t *__restrict__ offsets, uint32_t bin, bool active) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t result = 0;
-    unsigned long long pending = __ballot(active);
-    while (pending) {
-        const int leader = __builtin_ctzll(pending);
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
-        const unsigned long long same = __ballot(active && bin == b) & pending;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&offsets[b], (uint32_t)__popcll(same));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if ((same >> lane) & 1ull) result = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        pending &= ~same;
-    }
-    return result;
-}
-__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id, uint32_t *__restrict__ offsets,
+// position of every active ray in the direction-sorted list: start of its cell + rank in the cell
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id,
+                                                     const uint32_t *__restrict__ bin_rank,
+                                                     const uint32_t *__restrict__ offsets,
                                                      uint32_t *__restrict__ active_rid) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // the ray count is a multiple of the block size
     uint32_t bin = bin_id[rid];
-    bool active = bin != 0xffffffffu;
-    uint32_t pos = wave_bin_slot(offsets, bin, active);
-    if (active) active_rid[pos] = rid;
+    if (bin != 0xffffffffu) active_rid[offsets[bin] + bin_rank[rid]] = rid;
 }
 
 // Offsets of the direction bins, with every run of 16 consecutive bins (a 4x4 patch of cells on
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist)
     uint32_t sum = 0;
 #pragma unroll
     for (int i = 0; i < RT_PATCH / 4; i++) { v[i] = src[i]; sum += v[i].x + v[i].y + v[i].z + v[i].w; }
-    const uint32_t padded = (sum + 255u) & ~255u;
+    const uint32_t padded = (sum + (64u * PACKET_RAYS - 1u)) / (64u * PACKET_RAYS) * (64u * PACKET_RAYS);
     part[c] = padded;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -605,6 +611,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 
 template <int KIND>
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *__restrict__ L1,
+                                                                  const float *__restrict__ L1s,
                                                                   const float4 *__restrict__ L2, int n_padded,
                                                                   const float4 *__restrict__ ray32, uint32_t n_rays,
                                                                   const uint32_t *__restrict__ active_rid,
@@ -612,21 +619,31 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
                                                                   uint32_t *__restrict__ cand,
                                                                   uint32_t *__restrict__ cand_cnt,
                                                                   unsigned long long *__restrict__ counters) {
+    __shared__ float4 lds[2][PRIM_TILE];
+    __shared__ float lds_s[2][PRIM_TILE];
     const uint32_t t = threadIdx.x, lane = t & 63u;
     const uint32_t total = active_rid ? *n_active : n_rays;
-    if (blockIdx.x * RAYS_PER_TILE >= total) return;
-    // With a sorted list a wave takes 64*RAYS_PER_THREAD CONSECUTIVE entries (rays that point the
-    // same way); without one it keeps the screen tiling of rid_to_xy.
-    const uint32_t base = active_rid ? blockIdx.x * RAYS_PER_TILE + (t >> 6) * (64 * RAYS_PER_THREAD) + lane
-                                     : blockIdx.x * RAYS_PER_TILE + t;
-    const uint32_t stride = active_rid ? 64u : (uint32_t)SEARCH_THREADS;
-    float rx[RAYS_PER_THREAD], ry[RAYS_PER_THREAD], rz[RAYS_PER_THREAD], rw[RAYS_PER_THREAD];
-    uint32_t cnt[RAYS_PER_THREAD], rid[RAYS_PER_THREAD];
-    bool live[RAYS_PER_THREAD];
+    if (blockIdx.x * PACKET_BLOCK_RAYS >= total) return;
+    // A wave owns PACKET_RAYS rays per lane.  With a sorted list these are 64*PACKET_RAYS
+    // CONSECUTIVE entries (rays that point the same way).  Without one (camera rays) the workgroup
+    // covers PACKET_RAYS/RAYS_PER_THREAD neighbouring screen tiles and each wave takes adjacent
+    // wave-quarters of one of them, so its rays still form one compact block of pixels.
+    const uint32_t wave = t >> 6;
+    float rx[PACKET_RAYS], ry[PACKET_RAYS], rz[PACKET_RAYS], rw[PACKET_RAYS];
+    uint32_t cnt[PACKET_RAYS], rid[PACKET_RAYS];
+    bool live[PACKET_RAYS];
     float sx = 0.f, sy = 0.f, sz = 0.f, nact = 0.f, msq_max = 0.f;
 #pragma unroll
-    for (int r = 0; r < RAYS_PER_THREAD; r++) {
-        const uint32_t slot = base + r * stride;
+    for (int r = 0; r < PACKET_RAYS; r++) {
+        uint32_t slot;
+        if (active_rid) {
+            slot = blockIdx.x * PACKET_BLOCK_RAYS + wave * (64 * PACKET_RAYS) + r * 64 + lane;
+        } else {
+            // quarter-waves of the screen tiling, numbered consecutively over the workgroup's tiles
+            const uint32_t q = wave * (PACKET_RAYS / RAYS_PER_THREAD) + (uint32_t)r / RAYS_PER_THREAD;
+            const uint32_t tile = blockIdx.x * (PACKET_RAYS / RAYS_PER_THREAD) + q / 4;
+            slot = tile * RAYS_PER_TILE + ((uint32_t)r % RAYS_PER_THREAD) * SEARCH_THREADS + (q % 4) * 64 + lane;
+        }
         live[r] = slot < total;
         rid[r] = active_rid ? (live[r] ? active_rid[slot] : 0xffffffffu) : slot;
         if (rid[r] == 0xffffffffu) live[r] = false;
@@ -648,7 +665,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
         ax = sx * inv; ay = sy * inv; az = sz * inv;
         float lo = 1.f;
 #pragma unroll
-        for (int r = 0; r < RAYS_PER_THREAD; r++)
+        for (int r = 0; r < PACKET_RAYS; r++)
             if (rx[r] == rx[r]) lo = fminf(lo, __builtin_fmaf(rz[r], az, __builtin_fmaf(ry[r], ay, rx[r] * ax)));
         cosb = fmaxf(wave_min_f(lo) - 2e-6f, -1.f);
         sinb = sqrtf(fmaxf(0.f, 1.f - cosb * cosb));
@@ -658,7 +675,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
         ax = sx * inv; ay = sy * inv;
         float far = 0.f;
 #pragma unroll
-        for (int r = 0; r < RAYS_PER_THREAD; r++)
+        for (int r = 0; r < PACKET_RAYS; r++)
             if (rx[r] == rx[r]) {
                 float du = rx[r] - ax, dv = ry[r] - ay;
                 far = fmaxf(far, __builtin_fmaf(du, du, dv * dv));
@@ -668,50 +685,85 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
         rho = rho * (1.f + 1e-5f) + 4e-6f * (fabsf(ax) + fabsf(ay) + rho);
         everything = !(rho == rho) || !(rho < 3.0e38f);
     }
+    // The table is staged through LDS once per workgroup (512 records per step, double buffered,
+    // one barrier per step) and every wave tests all of it against its own beam: a quarter of the
+    // L2 traffic of four waves streaming the table separately.
     uint32_t n_surv = 0;
-    if (nact > 0.f) {
-        const int n_chunks = n_padded / 64; // a multiple of 8
-        // four table reads are kept in flight per wave: the loop is bound by L2 latency otherwise
-        for (int c0 = 0; c0 < n_chunks; c0 += 4) {
-            float4 pc[4];
+    const bool wave_live = nact > 0.f;
+    if (everything) { cosb = -1.f; sinb = 0.f; rho = __builtin_inff(); } // beam = all directions
+    const float neg_cosb = -cosb, neg_sinb = -sinb;
+    const int n_tiles = n_padded / PRIM_TILE;
+    float4 s0 = L1[t], s1 = L1[t + SEARCH_THREADS];
+    float e0 = 0.f, e1 = 0.f;
+    if (KIND == 1) { e0 = L1s[t]; e1 = L1s[t + SEARCH_THREADS]; }
+    lds[0][t] = s0; lds[0][t + SEARCH_THREADS] = s1;
+    if (KIND == 1) { lds_s[0][t] = e0; lds_s[0][t + SEARCH_THREADS] = e1; }
+    __syncthreads();
+    for (int tile = 0; tile < n_tiles; tile++) {
+        const int cur = tile & 1;
+        if (tile + 1 < n_tiles) {
+            s0 = L1[(size_t)(tile + 1) * PRIM_TILE + t];
+            s1 = L1[(size_t)(tile + 1) * PRIM_TILE + t + SEARCH_THREADS];
+            if (KIND == 1) {
+                e0 = L1s[(size_t)(tile + 1) * PRIM_TILE + t];
+                e1 = L1s[(size_t)(tile + 1) * PRIM_TILE + t + SEARCH_THREADS];
+            }
+        }
+        if (wave_live) {
+            // beam tests of the whole tile first, in straight-line code (eight independent chains
+            // hide the LDS and ALU latencies), then one branch decides whether any survivor needs work
+            unsigned long long masks[PRIM_TILE / 64];
+            unsigned long long any = 0ull;
 #pragma unroll
-            for (int u = 0; u < 4; u++) pc[u] = L1[(size_t)(c0 + u) * 64 + lane];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float4 p = pc[u];
-                const int chunk = c0 + u;
+            for (int u = 0; u < PRIM_TILE / 64; u++) {
+                const float4 p = lds[cur][u * 64 + lane];
                 bool surv;
                 if (KIND == 1) {
-                    const float ct = -p.w; // cosine threshold of the primitive's cone (2 = never, -2 = always)
+                    // cone (axis o, half angle theta) meets beam (axis a, half angle beta) iff
+                    // a.o >= cos(theta + beta), or theta + beta >= pi.  p.w = -cos(theta).
+                    const float st = lds_s[cur][u * 64 + lane];
                     const float ca = __builtin_fmaf(az, p.z, __builtin_fmaf(ay, p.y, ax * p.x));
-                    const float ctc = fminf(fmaxf(ct, -1.f), 1.f);
-                    const float st = sqrtf(fmaxf(0.f, 1.f - ctc * ctc));
-                    const float rhs = __builtin_fmaf(ctc, cosb, -st * sinb) - 4e-6f; // cos(theta + beta)
-                    surv = (ct < 1.5f) && (ct <= -1.5f || ctc < -cosb || ca >= rhs || everything);
+                    const float rhs = __builtin_fmaf(p.w, neg_cosb, __builtin_fmaf(st, neg_sinb, -4e-6f));
+                    surv = (ca >= rhs) || (p.w >= cosb); // second term: theta + beta >= pi, and the "always" records
                 } else {
+                    // circle (centre c, radius R) meets disc (centre a, radius rho) iff |c - a| <= R + rho
                     const float du = p.x - ax, dv = p.y - ay;
                     const float d2 = __builtin_fmaf(du, du, dv * dv);
-                    const float R = sqrtf(fmaxf(p.z, 0.f)) + rho;
-                    surv = (p.z >= 0.f) && (d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq_max) || everything);
+                    const float R = p.w + rho;
+                    surv = d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq_max);
                 }
-                unsigned long long mask = __ballot(surv);
-                n_surv += (uint32_t)__popcll(mask);
-                while (mask) {
-                    const int i = __builtin_ctzll(mask);
-                    mask &= mask - 1ull;
-                    float4 q;
-                    q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
-                    const uint32_t prim = (uint32_t)(chunk * 64 + i);
+                masks[u] = __ballot(surv);
+                any |= masks[u];
+            }
+            if (any) {
 #pragma unroll
-                    for (int r = 0; r < RAYS_PER_THREAD; r++)
-                        if (pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f))
-                            append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                for (int u = 0; u < PRIM_TILE / 64; u++) {
+                    unsigned long long mask = masks[u];
+                    if (!mask) continue;
+                    n_surv += (uint32_t)__popcll(mask);
+                    const float4 p = lds[cur][u * 64 + lane];
+                    while (mask) {
+                        const int i = __builtin_ctzll(mask);
+                        mask &= mask - 1ull;
+                        float4 q;
+                        q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
+                        const uint32_t prim = (uint32_t)(tile * PRIM_TILE + u * 64 + i);
+#pragma unroll
+                        for (int r = 0; r < PACKET_RAYS; r++)
+                            if (pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f))
+                                append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                    }
                 }
             }
         }
+        if (tile + 1 < n_tiles) {
+            lds[cur ^ 1][t] = s0; lds[cur ^ 1][t + SEARCH_THREADS] = s1;
+            if (KIND == 1) { lds_s[cur ^ 1][t] = e0; lds_s[cur ^ 1][t + SEARCH_THREADS] = e1; }
+        }
+        __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < RAYS_PER_THREAD; r++)
+    for (int r = 0; r < PACKET_RAYS; r++)
         if (live[r]) cand_cnt[rid[r]] = cnt[r];
     if (lane == 0 && n_surv) {
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
@@ -844,8 +896,8 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     n_shadow = light_prepare(sh, 0, next, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w, bin);
     } while (0);
     if (next.binned) { // all lanes of the wave arrive here
-        if (rid < f.n_rays) w.bin_id[rid] = bin;
-        wave_bin_count(w.bin_hist, bin, bin != 0xffffffffu);
+        const uint32_t rank = wave_bin_rank(w.bin_hist, bin, bin != 0xffffffffu);
+        if (rid < f.n_rays) { w.bin_id[rid] = bin; w.bin_rank[rid] = rank; }
     }
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
@@ -899,8 +951,8 @@ __global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView s
                              w.rec_cm1[rid], (cm0 >> 24) & 1u, rid, w, bin);
     } while (0);
     if (next.binned) { // all lanes of the wave arrive here
-        if (rid < f.n_rays) w.bin_id[rid] = bin;
-        wave_bin_count(w.bin_hist, bin, bin != 0xffffffffu);
+        const uint32_t rank = wave_bin_rank(w.bin_hist, bin, bin != 0xffffffffu);
+        if (rid < f.n_rays) { w.bin_id[rid] = bin; w.bin_rank[rid] = rank; }
     }
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
@@ -986,6 +1038,7 @@ struct rt355_scene {
     std::vector<void *> owned;
     // per-render bundle tables and per-ray workspace (grown on demand)
     float4 *L1 = nullptr, *L2 = nullptr;
+    float *L1s = nullptr;
     Work work{};
     uint32_t work_rays = 0;
     DLight *d_lights = nullptr; int lights_cap = 0;
@@ -1108,7 +1161,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.rec_pre, w.ray32, w.cand_cnt, w.cand,
-                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id};
+                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
     w = Work{};
@@ -1125,6 +1178,7 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     for (void *p : sc->owned) (void)hipFree(p);
     if (sc->L1) (void)hipFree(sc->L1);
     if (sc->L2) (void)hipFree(sc->L2);
+    if (sc->L1s) (void)hipFree(sc->L1s);
     if (sc->d_lights) (void)hipFree(sc->d_lights);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
@@ -1136,6 +1190,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
     if (!sc->L1) {
         HIP_TRY(hipMalloc((void **)&sc->L1, (size_t)sc->n_padded * sizeof(float4)));
         HIP_TRY(hipMalloc((void **)&sc->L2, (size_t)sc->n_padded * 3 * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&sc->L1s, (size_t)sc->n_padded * sizeof(float)));
     }
     while ((int)sc->ev_search.size() < 2 * n_bundles) {
         hipEvent_t e;
@@ -1156,9 +1211,10 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, (size_t)CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.active_rid, (n + RT_BINS / RT_PATCH * 256) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.active_rid, (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_hist, (RT_BINS + 2) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_id, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.bin_rank, n * sizeof(uint32_t)));
     sc->work_rays = n_rays;
     return RT355_OK;
 }
@@ -1270,15 +1326,15 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         const Bundle &b = bundles[bi];
         const bool is_eye = (bi == 0);
         if (b.kind == 1)
-            hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, b.o, is_eye ? 1 : 0, sc->n_padded, sc->L1, sc->L2);
+            hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, b.o, is_eye ? 1 : 0, sc->n_padded, sc->L1, sc->L2, sc->L1s);
         else
             hipLaunchKernelGGL(k_bundle_direction, dim3(setup_blocks), dim3(256), 0, st, sc->view, b, ray_dir[bi], sc->n_padded, sc->L1, sc->L2);
         const uint32_t *list = nullptr, *total = nullptr;
         if (b.binned) { // the producer of the rays counted them into direction bins: order them
             hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, sc->work.bin_hist);
             // padding slots of the sorted list stay 0xffffffff = no ray
-            HIP_TRY(hipMemsetAsync(sc->work.active_rid, 0xff, ((size_t)f.n_rays + RT_BINS / RT_PATCH * 256) * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.bin_id, sc->work.bin_hist, sc->work.active_rid);
+            HIP_TRY(hipMemsetAsync(sc->work.active_rid, 0xff, ((size_t)f.n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS) * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.bin_id, sc->work.bin_rank, sc->work.bin_hist, sc->work.active_rid);
             list = sc->work.active_rid; total = sc->work.bin_hist + RT_BINS + 1;
         } else if (!is_eye) { // shadow bundles are sparse: compact their active rays first
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count);
@@ -1288,11 +1344,12 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
-            const unsigned n_blocks = is_eye ? n_tiles : n_tiles + (RT_BINS / RT_PATCH * 256 + RAYS_PER_TILE - 1) / RAYS_PER_TILE;
+            const size_t n_slots = is_eye ? (size_t)f.n_rays : (size_t)f.n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS;
+            const unsigned n_blocks = (unsigned)((n_slots + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
             if (b.kind == 1)
-                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
             else
-                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
         } else if (b.kind == 1)
             hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
         else

@@ -26,10 +26,10 @@ def main(paths):
         if rows:
             print(f"{'kernel':32s} {'counter':26s} {'sum over dispatches':>22s} {'dispatches':>10s} {'per dispatch':>18s}")
             for name, c, v, n in rows:
-                if name.startswith("k_"):
+                if name.startswith("k_") or name.startswith("void k_"):
                     print(f"{name.split('(')[0][:32]:32s} {c:26s} {v:22.0f} {n:10d} {v/n:18.0f}")
         regs = list(cur.execute("select distinct name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, "
-                                "grid_x, workgroup_x from kernels where name like 'k_%'"))
+                                "grid_x, workgroup_x from kernels where name like 'k_%' or name like 'void k_%'"))
         print(f"{'kernel':32s} vgpr agpr sgpr lds scratch grid wg")
         for r in regs:
             print(f"{r[0].split('(')[0][:32]:32s} " + " ".join(str(x) for x in r[1:]))
