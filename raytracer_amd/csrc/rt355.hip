@@ -41,7 +41,11 @@
 #ifndef PACKET_RAYS
 #define PACKET_RAYS 4 // rays per lane of the packet search: a multiple of RAYS_PER_THREAD
 #endif
-#define PACKET_BLOCK_RAYS (SEARCH_THREADS * PACKET_RAYS)
+#ifndef PACKET_WAVES
+#define PACKET_WAVES 4 // waves per workgroup of the packet search
+#endif
+#define PACKET_THREADS (64 * PACKET_WAVES)
+#define PACKET_BLOCK_RAYS (PACKET_THREADS * PACKET_RAYS)
 #ifndef PRIM_TILE
 #define PRIM_TILE 512       // primitives staged in LDS per step (8 KiB, double buffered)
 #endif
@@ -98,6 +102,11 @@ __device__ __forceinline__ void wave_count(unsigned long long *counters, int whi
     if ((threadIdx.x & 63u) == 0 && v)
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + which], (unsigned long long)v);
 }
+
+#ifdef RT355_DEBUG_TIMES
+// debug build only: per-workgroup time stamps of the packet search (100 MHz wall clock)
+__device__ unsigned long long *g_dbg_times = nullptr;
+#endif
 
 __device__ __forceinline__ float4 nan4() {
     float q = __builtin_nanf("");
@@ -483,10 +492,9 @@ __device__ __forceinline__ float pair_margin(float x, float y, float z, const fl
 }
 
 template <int KIND>
-__device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t prim, float x, float y,
-                                                 float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
-                                                 uint32_t &cnt) {
-    const float4 a = L2[3 * (size_t)prim], b = L2[3 * (size_t)prim + 1], c = L2[3 * (size_t)prim + 2];
+__device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, const float4 &c, uint32_t prim, float x,
+                                            float y, float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
+                                            uint32_t &cnt) {
     float ea, eb, ec, floor_;
     if (KIND == 1) { // direction inside the pyramid over the triangle
         ea = __builtin_fmaf(z, a.z, __builtin_fmaf(y, a.y, x * a.x));
@@ -503,6 +511,13 @@ __device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, 
         if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = prim;
         cnt++;
     }
+}
+template <int KIND>
+__device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t prim, float x, float y,
+                                                 float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
+                                                 uint32_t &cnt) {
+    const float4 a = L2[3 * (size_t)prim], b = L2[3 * (size_t)prim + 1], c = L2[3 * (size_t)prim + 2];
+    append_rows<KIND>(a, b, c, prim, x, y, z, lin, rid, n_rays, cand, cnt);
 }
 
 template <int KIND>
@@ -582,14 +597,15 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
 }
 
 // ---- packet search: one beam test per (wave, primitive), pair tests only for the survivors -----------
-// The 256 rays of a wave are neighbours on screen, so they fit in a narrow beam: a cone around
-// their mean direction (common-origin bundles) or a disc around their mean projected origin
-// (common-direction bundles).  A primitive whose bounding cone / circle misses the beam cannot be a
-// candidate of any ray of the wave.  Lanes take 64 primitives at a time (one coalesced 1 KiB read
-// of the table per wave and chunk, served from L2), test beam against bound, and __ballot the
-// survivors; only those (a handful per wave) get the per-ray test of k_search.  Every primitive
-// is still looked at by every wave -- there is no hierarchy over the primitives -- but the work per
-// (ray, primitive) pair drops from 3.6 VALU instructions to ~0.05.
+// The 1024 rays of a workgroup are neighbours (on screen for camera rays, in direction for the
+// sorted shadow rays), so they fit in a narrow beam: a cone around their mean direction
+// (common-origin bundles) or a disc around their mean projected origin (common-direction bundles).
+// A primitive whose bounding cone / circle misses the beam cannot be a candidate of any of those
+// rays.  Lanes take 64 primitives at a time (one coalesced 1 KiB read of the table, served from
+// L2), test beam against bound, and __ballot the survivors; only those (a handful per workgroup)
+// get the per-ray test of k_search.  Every primitive is still looked at by every workgroup --
+// there is no hierarchy over the primitives -- but the work per (ray, primitive) pair drops from
+// 3.6 VALU instructions to ~0.01.
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -609,8 +625,13 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+#ifndef PACKET_PER_WAVE
+#define PACKET_PER_WAVE 4 // chunks of 64 primitives a wave tests per round (all loads in flight together)
+#endif
+#define PACKET_ROUND (PACKET_PER_WAVE * PACKET_WAVES) // chunks per round, one barrier per round
+static_assert(PACKET_ROUND <= 64, "one lane per chunk mask of a round");
 template <int KIND>
-__global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *__restrict__ L1,
+__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *__restrict__ L1,
                                                                   const float *__restrict__ L1s,
                                                                   const float4 *__restrict__ L2, int n_padded,
                                                                   const float4 *__restrict__ ray32, uint32_t n_rays,
@@ -619,16 +640,20 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
                                                                   uint32_t *__restrict__ cand,
                                                                   uint32_t *__restrict__ cand_cnt,
                                                                   unsigned long long *__restrict__ counters) {
-    __shared__ float4 lds[2][PRIM_TILE];
-    __shared__ float lds_s[2][PRIM_TILE];
-    const uint32_t t = threadIdx.x, lane = t & 63u;
+    // The workgroup's rays (PACKET_WAVES x 256) share ONE beam.  Its waves split the primitive table
+    // between them (chunk c goes to wave c % PACKET_WAVES, read straight from L2 with eight loads
+    // in flight), so the table is read once per workgroup and each wave does its share of the beam
+    // tests.  Survivor masks are exchanged through LDS, one barrier per round; then every wave
+    // walks the masks in primitive order, filters the surviving chunks with its OWN narrower beam,
+    // and runs the per-ray test for what is left.
+    __shared__ unsigned long long masks[2][PACKET_ROUND];
+    __shared__ float red[PACKET_WAVES][8];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t total = active_rid ? *n_active : n_rays;
     if (blockIdx.x * PACKET_BLOCK_RAYS >= total) return;
-    // A wave owns PACKET_RAYS rays per lane.  With a sorted list these are 64*PACKET_RAYS
-    // CONSECUTIVE entries (rays that point the same way).  Without one (camera rays) the workgroup
-    // covers PACKET_RAYS/RAYS_PER_THREAD neighbouring screen tiles and each wave takes adjacent
-    // wave-quarters of one of them, so its rays still form one compact block of pixels.
-    const uint32_t wave = t >> 6;
+#ifdef RT355_DEBUG_TIMES
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     float rx[PACKET_RAYS], ry[PACKET_RAYS], rz[PACKET_RAYS], rw[PACKET_RAYS];
     uint32_t cnt[PACKET_RAYS], rid[PACKET_RAYS];
     bool live[PACKET_RAYS];
@@ -636,12 +661,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
 #pragma unroll
     for (int r = 0; r < PACKET_RAYS; r++) {
         uint32_t slot;
-        if (active_rid) {
+        if (active_rid) { // sorted list: a wave takes 64*PACKET_RAYS consecutive entries
             slot = blockIdx.x * PACKET_BLOCK_RAYS + wave * (64 * PACKET_RAYS) + r * 64 + lane;
-        } else {
-            // quarter-waves of the screen tiling, numbered consecutively over the workgroup's tiles
+        } else {          // camera rays: quarter-waves of the screen tiling, numbered over the workgroup's tiles
             const uint32_t q = wave * (PACKET_RAYS / RAYS_PER_THREAD) + (uint32_t)r / RAYS_PER_THREAD;
-            const uint32_t tile = blockIdx.x * (PACKET_RAYS / RAYS_PER_THREAD) + q / 4;
+            const uint32_t tile = blockIdx.x * (PACKET_WAVES * PACKET_RAYS / (4 * RAYS_PER_THREAD)) + q / 4;
             slot = tile * RAYS_PER_TILE + ((uint32_t)r % RAYS_PER_THREAD) * SEARCH_THREADS + (q % 4) * 64 + lane;
         }
         live[r] = slot < total;
@@ -654,117 +678,180 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_packet(const float4 *
             if (KIND == 1) sz += q.z; else msq_max = fmaxf(msq_max, q.z);
         }
     }
-    // ---- the wave's beam
-    sx = wave_sum_f(sx); sy = wave_sum_f(sy); nact = wave_sum_f(nact);
-    float ax, ay, az = 0.f, cosb = -1.f, sinb = 0.f, rho = 0.f;
-    bool everything = false; // beam degenerate: test every primitive per ray
-    if (KIND == 1) {
-        sz = wave_sum_f(sz);
-        float len2 = sx * sx + sy * sy + sz * sz;
-        float inv = 1.0f / sqrtf(fmaxf(len2, 1e-30f));
-        ax = sx * inv; ay = sy * inv; az = sz * inv;
-        float lo = 1.f;
+    // ---- beams.  Each wave has its own (used to filter the workgroup's survivors before any
+    // per-ray work); the workgroup's is built from the per-wave sums through LDS.
+    sx = wave_sum_f(sx); sy = wave_sum_f(sy); sz = wave_sum_f(sz); nact = wave_sum_f(nact);
+    msq_max = wave_max_f(msq_max);
+    const bool wave_live = nact > 0.f;
+    if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; red[wave][3] = nact; red[wave][4] = msq_max; }
+    __syncthreads();
+    float bx = 0.f, by = 0.f, bz = 0.f, bn = 0.f, bmsq = 0.f;
 #pragma unroll
-        for (int r = 0; r < PACKET_RAYS; r++)
-            if (rx[r] == rx[r]) lo = fminf(lo, __builtin_fmaf(rz[r], az, __builtin_fmaf(ry[r], ay, rx[r] * ax)));
-        cosb = fmaxf(wave_min_f(lo) - 2e-6f, -1.f);
-        sinb = sqrtf(fmaxf(0.f, 1.f - cosb * cosb));
-        everything = !(len2 > 1e-12f);
-    } else {
-        float inv = 1.0f / fmaxf(nact, 1.f);
-        ax = sx * inv; ay = sy * inv;
-        float far = 0.f;
+    for (int v = 0; v < PACKET_WAVES; v++) {
+        bx += red[v][0]; by += red[v][1]; bz += red[v][2]; bn += red[v][3]; bmsq = fmaxf(bmsq, red[v][4]);
+    }
+    if (!(bn > 0.f)) { // nothing to search for in this workgroup (uniform)
+#pragma unroll
+        for (int r = 0; r < PACKET_RAYS; r++) if (live[r]) cand_cnt[rid[r]] = 0;
+        return;
+    }
+    // axis / centre of the wave beam (w*) and of the workgroup beam (g*), and their spreads
+    float wx, wy, wz = 0.f, gx, gy, gz = 0.f, w_spread, g_spread;
+    bool w_all = false, g_all = false; // degenerate beam: every primitive survives
+    if (KIND == 1) {
+        const float wl2 = sx * sx + sy * sy + sz * sz, gl2 = bx * bx + by * by + bz * bz;
+        const float wi = 1.0f / sqrtf(fmaxf(wl2, 1e-30f)), gi = 1.0f / sqrtf(fmaxf(gl2, 1e-30f));
+        wx = sx * wi; wy = sy * wi; wz = sz * wi;
+        gx = bx * gi; gy = by * gi; gz = bz * gi;
+        float wlo = 1.f, glo = 1.f;
 #pragma unroll
         for (int r = 0; r < PACKET_RAYS; r++)
             if (rx[r] == rx[r]) {
-                float du = rx[r] - ax, dv = ry[r] - ay;
-                far = fmaxf(far, __builtin_fmaf(du, du, dv * dv));
+                wlo = fminf(wlo, __builtin_fmaf(rz[r], wz, __builtin_fmaf(ry[r], wy, rx[r] * wx)));
+                glo = fminf(glo, __builtin_fmaf(rz[r], gz, __builtin_fmaf(ry[r], gy, rx[r] * gx)));
             }
-        msq_max = wave_max_f(msq_max);
-        rho = sqrtf(wave_max_f(far));
-        rho = rho * (1.f + 1e-5f) + 4e-6f * (fabsf(ax) + fabsf(ay) + rho);
-        everything = !(rho == rho) || !(rho < 3.0e38f);
+        w_spread = wave_min_f(wlo); g_spread = wave_min_f(glo);
+        w_all = !(wl2 > 1e-12f); g_all = !(gl2 > 1e-12f);
+    } else {
+        const float wi = 1.0f / fmaxf(nact, 1.f), gi = 1.0f / bn;
+        wx = sx * wi; wy = sy * wi; gx = bx * gi; gy = by * gi;
+        float wfar = 0.f, gfar = 0.f;
+#pragma unroll
+        for (int r = 0; r < PACKET_RAYS; r++)
+            if (rx[r] == rx[r]) {
+                float du = rx[r] - wx, dv = ry[r] - wy;
+                wfar = fmaxf(wfar, __builtin_fmaf(du, du, dv * dv));
+                du = rx[r] - gx; dv = ry[r] - gy;
+                gfar = fmaxf(gfar, __builtin_fmaf(du, du, dv * dv));
+            }
+        w_spread = wave_max_f(wfar); g_spread = wave_max_f(gfar);
     }
-    // The table is staged through LDS once per workgroup (512 records per step, double buffered,
-    // one barrier per step) and every wave tests all of it against its own beam: a quarter of the
-    // L2 traffic of four waves streaming the table separately.
-    uint32_t n_surv = 0;
-    const bool wave_live = nact > 0.f;
-    if (everything) { cosb = -1.f; sinb = 0.f; rho = __builtin_inff(); } // beam = all directions
-    const float neg_cosb = -cosb, neg_sinb = -sinb;
-    const int n_tiles = n_padded / PRIM_TILE;
-    float4 s0 = L1[t], s1 = L1[t + SEARCH_THREADS];
-    float e0 = 0.f, e1 = 0.f;
-    if (KIND == 1) { e0 = L1s[t]; e1 = L1s[t + SEARCH_THREADS]; }
-    lds[0][t] = s0; lds[0][t + SEARCH_THREADS] = s1;
-    if (KIND == 1) { lds_s[0][t] = e0; lds_s[0][t + SEARCH_THREADS] = e1; }
+    if (lane == 0) red[wave][5] = g_spread;
     __syncthreads();
-    for (int tile = 0; tile < n_tiles; tile++) {
-        const int cur = tile & 1;
-        if (tile + 1 < n_tiles) {
-            s0 = L1[(size_t)(tile + 1) * PRIM_TILE + t];
-            s1 = L1[(size_t)(tile + 1) * PRIM_TILE + t + SEARCH_THREADS];
-            if (KIND == 1) {
-                e0 = L1s[(size_t)(tile + 1) * PRIM_TILE + t];
-                e1 = L1s[(size_t)(tile + 1) * PRIM_TILE + t + SEARCH_THREADS];
-            }
+    float g_cos = -1.f, g_sin = 0.f, g_rho = 0.f, w_cos = -1.f, w_sin = 0.f, w_rho = 0.f;
+    if (KIND == 1) {
+        g_spread = red[0][5];
+#pragma unroll
+        for (int v = 1; v < PACKET_WAVES; v++) g_spread = fminf(g_spread, red[v][5]);
+        g_cos = fmaxf(g_spread - 2e-6f, -1.f); g_sin = sqrtf(fmaxf(0.f, 1.f - g_cos * g_cos));
+        w_cos = fmaxf(w_spread - 2e-6f, -1.f); w_sin = sqrtf(fmaxf(0.f, 1.f - w_cos * w_cos));
+    } else {
+        g_spread = red[0][5];
+#pragma unroll
+        for (int v = 1; v < PACKET_WAVES; v++) g_spread = fmaxf(g_spread, red[v][5]);
+        g_rho = sqrtf(g_spread); g_rho = g_rho * (1.f + 1e-5f) + 4e-6f * (fabsf(gx) + fabsf(gy) + g_rho);
+        w_rho = sqrtf(w_spread); w_rho = w_rho * (1.f + 1e-5f) + 4e-6f * (fabsf(wx) + fabsf(wy) + w_rho);
+        g_all = !(g_rho == g_rho) || !(g_rho < 3.0e38f);
+        w_all = !(w_rho == w_rho) || !(w_rho < 3.0e38f);
+    }
+    if (g_all) { g_cos = -1.f; g_sin = 0.f; g_rho = __builtin_inff(); }
+    if (w_all) { w_cos = -1.f; w_sin = 0.f; w_rho = __builtin_inff(); }
+
+    // does the bound of a primitive record meet a beam?
+    auto meets = [&](const float4 &p, float st, float ax_, float ay_, float az_, float cosb, float sinb,
+                     float rho, float msq) -> bool {
+        if (KIND == 1) {
+            // cone (axis o, half angle theta) meets beam (axis a, half angle beta) iff
+            // a.o >= cos(theta + beta), or theta + beta >= pi.  p.w = -cos(theta), st = sin(theta).
+            const float ca = __builtin_fmaf(az_, p.z, __builtin_fmaf(ay_, p.y, ax_ * p.x));
+            const float rhs = __builtin_fmaf(p.w, -cosb, __builtin_fmaf(st, -sinb, -4e-6f));
+            return (ca >= rhs) || (p.w >= cosb); // second term: theta + beta >= pi, and the "always" records
         }
+        // circle (centre c, radius R) meets disc (centre a, radius rho) iff |c - a| <= R + rho
+        const float du = p.x - ax_, dv = p.y - ay_;
+        const float d2 = __builtin_fmaf(du, du, dv * dv);
+        const float R = p.w + rho;
+        return d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq);
+    };
+
+    uint32_t n_surv = 0;
+    const int n_chunks = n_padded / 64;
+    const int n_rounds = (n_chunks + PACKET_ROUND - 1) / PACKET_ROUND;
+    float4 pc[PACKET_PER_WAVE];
+    float ps[PACKET_PER_WAVE];
+    auto fetch_round = [&](int round) {
+#pragma unroll
+        for (int k = 0; k < PACKET_PER_WAVE; k++) {
+            const int chunk = round * PACKET_ROUND + (int)wave + PACKET_WAVES * k;
+            const size_t at = (size_t)min(chunk, n_chunks - 1) * 64 + lane;
+            pc[k] = L1[at];
+            ps[k] = (KIND == 1) ? L1s[at] : 0.f;
+        }
+    };
+    fetch_round(0);
+    for (int round = 0; round < n_rounds; round++) {
+        const int buf = round & 1;
+        // ---- this wave's share of the workgroup-beam tests
+#pragma unroll
+        for (int k = 0; k < PACKET_PER_WAVE; k++) {
+            const int chunk = round * PACKET_ROUND + (int)wave + PACKET_WAVES * k;
+            const bool surv = meets(pc[k], ps[k], gx, gy, gz, g_cos, g_sin, g_rho, bmsq);
+            const unsigned long long m = (chunk < n_chunks) ? __ballot(surv) : 0ull;
+            if (lane == 0) masks[buf][wave + PACKET_WAVES * k] = m;
+        }
+        if (round + 1 < n_rounds) fetch_round(round + 1); // in flight across the barrier and the survivor walk
+        __syncthreads();
+        // ---- surviving chunks of the round, in primitive order.  A surviving chunk is reloaded
+        // whole (cone records and pyramid rows, five coalesced reads, the next chunk's already in
+        // flight), filtered with this wave's own beam, and only then come the per-ray tests, which
+        // take their operands from registers (readlane), never from memory.
         if (wave_live) {
-            // beam tests of the whole tile first, in straight-line code (eight independent chains
-            // hide the LDS and ALU latencies), then one branch decides whether any survivor needs work
-            unsigned long long masks[PRIM_TILE / 64];
-            unsigned long long any = 0ull;
+            const unsigned long long mine = (lane < PACKET_ROUND) ? masks[buf][lane] : 0ull;
+            unsigned long long which = __ballot(mine != 0ull);
+            float4 np, na, nb, nc; float nst = 0.f;
+            auto fetch_chunk = [&](int c) {
+                const size_t at = (size_t)(round * PACKET_ROUND + c) * 64 + lane;
+                np = L1[at]; nst = (KIND == 1) ? L1s[at] : 0.f;
+                na = L2[3 * at]; nb = L2[3 * at + 1]; nc = L2[3 * at + 2];
+            };
+            int c_next = which ? __builtin_ctzll(which) : 0;
+            if (which) fetch_chunk(c_next);
+            while (which) {
+                const int c = c_next;
+                which &= which - 1ull;
+                const float4 p = np, ra = na, rb = nb, rc = nc;
+                const float st = nst;
+                if (which) { c_next = __builtin_ctzll(which); fetch_chunk(c_next); }
+                const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, c);
+                const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), c);
+                const bool surv = meets(p, st, wx, wy, wz, w_cos, w_sin, w_rho, msq_max);
+                unsigned long long mask = __ballot(surv) & (((unsigned long long)m_hi << 32) | m_lo);
+                n_surv += (uint32_t)__popcll(mask);
+                while (mask) {
+                    const int i = __builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    float4 q;
+                    q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
+                    const uint32_t prim = (uint32_t)((round * PACKET_ROUND + c) * 64 + i);
+                    bool hit[PACKET_RAYS];
+                    bool any_hit = false;
 #pragma unroll
-            for (int u = 0; u < PRIM_TILE / 64; u++) {
-                const float4 p = lds[cur][u * 64 + lane];
-                bool surv;
-                if (KIND == 1) {
-                    // cone (axis o, half angle theta) meets beam (axis a, half angle beta) iff
-                    // a.o >= cos(theta + beta), or theta + beta >= pi.  p.w = -cos(theta).
-                    const float st = lds_s[cur][u * 64 + lane];
-                    const float ca = __builtin_fmaf(az, p.z, __builtin_fmaf(ay, p.y, ax * p.x));
-                    const float rhs = __builtin_fmaf(p.w, neg_cosb, __builtin_fmaf(st, neg_sinb, -4e-6f));
-                    surv = (ca >= rhs) || (p.w >= cosb); // second term: theta + beta >= pi, and the "always" records
-                } else {
-                    // circle (centre c, radius R) meets disc (centre a, radius rho) iff |c - a| <= R + rho
-                    const float du = p.x - ax, dv = p.y - ay;
-                    const float d2 = __builtin_fmaf(du, du, dv * dv);
-                    const float R = p.w + rho;
-                    surv = d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq_max);
-                }
-                masks[u] = __ballot(surv);
-                any |= masks[u];
-            }
-            if (any) {
-#pragma unroll
-                for (int u = 0; u < PRIM_TILE / 64; u++) {
-                    unsigned long long mask = masks[u];
-                    if (!mask) continue;
-                    n_surv += (uint32_t)__popcll(mask);
-                    const float4 p = lds[cur][u * 64 + lane];
-                    while (mask) {
-                        const int i = __builtin_ctzll(mask);
-                        mask &= mask - 1ull;
-                        float4 q;
-                        q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
-                        const uint32_t prim = (uint32_t)(tile * PRIM_TILE + u * 64 + i);
+                    for (int r = 0; r < PACKET_RAYS; r++) {
+                        hit[r] = pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f);
+                        any_hit |= hit[r];
+                    }
+                    if (any_hit) { // some ray is inside the cone / circle: pyramid / edge-function rows
+                        float4 ea, eb, ec;
+                        ea.x = lane_bcast(ra.x, i); ea.y = lane_bcast(ra.y, i); ea.z = lane_bcast(ra.z, i); ea.w = 0.f;
+                        eb.x = lane_bcast(rb.x, i); eb.y = lane_bcast(rb.y, i); eb.z = lane_bcast(rb.z, i); eb.w = 0.f;
+                        ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
 #pragma unroll
                         for (int r = 0; r < PACKET_RAYS; r++)
-                            if (pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f))
-                                append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                            if (hit[r]) append_rows<KIND>(ea, eb, ec, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
                     }
                 }
             }
         }
-        if (tile + 1 < n_tiles) {
-            lds[cur ^ 1][t] = s0; lds[cur ^ 1][t + SEARCH_THREADS] = s1;
-            if (KIND == 1) { lds_s[cur ^ 1][t] = e0; lds_s[cur ^ 1][t + SEARCH_THREADS] = e1; }
-        }
-        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < PACKET_RAYS; r++)
         if (live[r]) cand_cnt[rid[r]] = cnt[r];
+#ifdef RT355_DEBUG_TIMES
+    if (g_dbg_times && lane == 0) {
+        unsigned long long *rec = g_dbg_times + ((size_t)blockIdx.x * PACKET_WAVES + wave) * 4;
+        rec[0] = dbg_t0; rec[1] = wall_clock64(); rec[2] = n_surv; rec[3] = (unsigned long long)nact;
+    }
+#endif
     if (lane == 0 && n_surv) {
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
 #ifdef RT355_DEBUG_SURVIVORS
@@ -1347,9 +1434,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             const size_t n_slots = is_eye ? (size_t)f.n_rays : (size_t)f.n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS;
             const unsigned n_blocks = (unsigned)((n_slots + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
             if (b.kind == 1)
-                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
             else
-                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
         } else if (b.kind == 1)
             hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
         else
@@ -1428,6 +1515,15 @@ extern "C" int rt355_scene_search_kernel_ms(rt355_scene *sc, double *ms_sum, int
     *launches = sc->search_launches;
     return RT355_OK;
 }
+
+#ifdef RT355_DEBUG_TIMES
+// debug build only: device buffer of 16 * workgroups unsigned long longs, or null to switch off
+extern "C" int rt355_debug_set_times_buffer(void *dptr) {
+    unsigned long long *p = (unsigned long long *)dptr;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_times), &p, sizeof p));
+    return RT355_OK;
+}
+#endif
 
 extern "C" int rt355_scene_search_launch_ms(rt355_scene *sc, int32_t index, double *ms) {
     if (!sc || !ms || index < 0 || index >= (int32_t)sc->launch_ms.size()) return fail(RT355_ERR_ARG, "bad launch index");
