@@ -2,6 +2,11 @@
 """Benchmark of the accelerated render path: Mrays/s (primary + shadow) at 3840x2160.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shard frames|slabs]
+                    [--mode packet|allpairs]
+
+The headline run uses the library's default search (packet: workgroup beam culling, then pair
+tests); the all-pairs search (every ray x every primitive in fp32, the FP32-VALU-bound kernel) is
+timed beside it on rank 0 at N = 1 and reported in "all_pairs" with its own roofline.
 
 One step = one frame of the workload rendered by rt355_render_device into a framebuffer that
 stays in HBM (scene, tables and framebuffer are all device-resident when the timed region
@@ -26,6 +31,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (= the f32-input MFMA peak), datasheet
+PEAK_HBM_GBS = 8000.0     # HBM3E peak, datasheet (about 6300 GB/s is achievable)
+PEAK_L2_GBS = 34500.0     # aggregate L2 bandwidth of the 8 XCDs (measured figure of the microarchitecture guide)
 # flops per ray/primitive test of the REFERENCE formulas (common sub-expressions shared):
 ALGO_FLOPS = {"sphere": 18.0, "plane": 14.0, "tri_front": 50.0, "tri_culled": 13.0}
 # flops the search kernel EXECUTES per pair: 3 FMA (6) + its share of the max-fold (8 max3 per
@@ -98,6 +105,43 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads):
                       f"{st['shadow_rays']} shadow rays, {dt:.2f} s)"}
 
 
+def resolve_bytes(stats, n_rays_padded, n_lights, w, h):
+    """Algorithmic HBM bytes of the fp64 resolve kernels of one frame (per-ray records are SoA):
+    every ray slot reads/writes its 4-byte object id once per kernel; a hit writes its record once
+    (ph, nh, npe = 72 B, obj/cm0/cm1/sum/pre = 20 B) and per light reads ph, pre, sum (32 B), writes sum
+    (4 B) and, unless it is the last light, reads nh, npe, cm0, cm1 (56 B) and writes pre, the fp32 shadow
+    ray and its direction bin (28 B); every ray with a search reads its candidate count and ids; the
+    last kernel stores 3 bytes per pixel."""
+    hits, cands = stats["primary_hits"], stats["exact_tests"]
+    rays = stats["primary_rays"] + stats["shadow_rays"]
+    b = n_rays_padded * 4 * (1 + n_lights)
+    b += hits * (92 + 28 * (1 if n_lights else 0))
+    b += hits * n_lights * 36 + hits * max(0, n_lights - 1) * (56 + 28)
+    b += rays * 4 + cands * 4 + w * h * 3
+    return float(b)
+
+
+def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None):
+    """K frames back to back; returns per-frame averages of the HIP-event kernel times and the stats."""
+    import time as _t
+    acc = {"search_ms": 0.0, "search_launches": 0, "resolve_ms": 0.0, "resolve_launches": 0, "pairs": 0}
+    stats = None
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        r.render_device(cam, shader, o, fb.data_ptr(), stream)
+        if extra_step:
+            extra_step()
+        stats = r.sync()  # waits for this frame's events (frames are serial on the stream anyway)
+        ms, n = r.search_kernel_ms()
+        acc["search_ms"] += ms; acc["search_launches"] += n
+        ms, n = r.resolve_kernel_ms()
+        acc["resolve_ms"] += ms; acc["resolve_launches"] += n
+        acc["pairs"] += stats["pair_tests"]
+    acc["wall_s"] = None  # filled by the caller around its own barriers
+    acc["loop_s"] = _t.perf_counter() - t0
+    return acc, stats
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,8 +149,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="spheres10k_8lights_4k")
     ap.add_argument("--shard", choices=["frames", "slabs"], default="frames")
-    ap.add_argument("--mode", choices=["fast", "packet"], default="fast",
-                    help="fast = all-pairs fp32 search; packet = per-wave beam culling before the pair tests")
+    ap.add_argument("--mode", choices=["packet", "allpairs"], default="packet",
+                    help="search of the headline run: packet = workgroup beam culling before the pair tests "
+                         "(library default); allpairs = fp32 test of every ray/primitive pair")
+    ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -129,42 +175,29 @@ def main():
 
     from raytracer_amd import binding as B
     from raytracer_amd.api import Renderer
+    from raytracer_amd.sharding import gather_frame, slab_rows
 
     scene, shader, cam, w, h = build_workload(args.workload)
     r = Renderer(scene)
     fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
-    from raytracer_amd.sharding import gather_frame, slab_rows
-    mode = B.MODE_PACKET if args.mode == "packet" else B.MODE_FAST
+    mode = B.MODE_PACKET if args.mode == "packet" else B.MODE_ALLPAIRS
     if args.shard == "slabs" and world > 1:
         b, e = slab_rows(h, world)[rank]
         o = B.opts(w, h, row_begin=b, row_end=e, mode=mode)
     else:
         o = B.opts(w, h, mode=mode)
     stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        r.render_device(cam, shader, o, fb.data_ptr(), stream)
-        if args.shard == "slabs" and world > 1:
-            gather_frame(fb, rank, world, dst=0)  # the only exchange of the path: the final frame
+    gather = (lambda: gather_frame(fb, rank, world, dst=0)) if (args.shard == "slabs" and world > 1) else None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_frames(r, cam, shader, o, fb, stream, args.warmup, gather)
     barrier()
-    search_ms, search_launches, pairs_total = 0.0, 0, 0
     t0 = time.perf_counter()
-    stats = None
-    for _ in range(args.steps):
-        step()
-        stats = r.sync()  # waits for this frame's events (frames are serial on the stream anyway)
-        ms, n = r.search_kernel_ms()
-        search_ms += ms
-        search_launches += n
-        pairs_total += stats["pair_tests"] if n else 0
+    acc, stats = run_frames(r, cam, shader, o, fb, stream, args.steps, gather)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -177,9 +210,25 @@ def main():
     else:
         rays_step = float(stats["primary_rays"] + stats["shadow_rays"])
 
+    def valu_roofline(acc, stats, steps):
+        """FP32-VALU roofline of the all-pairs search kernel."""
+        avg_ms = acc["search_ms"] / acc["search_launches"]
+        pairs_per_launch = acc["pairs"] / acc["search_launches"]
+        exec_tflops = pairs_per_launch * EXEC_FLOPS_PER_PAIR / (avg_ms * 1e-3) / 1e12
+        algo = algorithmic_flops(scene, shader, cam, stats) * steps / acc["search_launches"]
+        algo_tflops = algo / (avg_ms * 1e-3) / 1e12
+        return {"bound": "valu_fp32", "kernel": "k_search", "achieved": round(exec_tflops, 2), "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(exec_tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                "launches_per_frame": acc["search_launches"] // steps, "avg_launch_ms": round(avg_ms, 4),
+                "pairs_per_launch": pairs_per_launch, "flops_per_pair_executed": EXEC_FLOPS_PER_PAIR,
+                "reference_formula_equivalent": {"tflops": round(algo_tflops, 2),
+                                                 "frac_of_peak": round(algo_tflops / PEAK_FP32_TFLOPS, 4),
+                                                 "flops_per_test": ALGO_FLOPS}}
+
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         value = rays_step * args.steps / dt / 1e6
+        n_rays_padded = ((w + 31) // 32) * (((o.row_end or h) - o.row_begin + 31) // 32) * 1024
         out = {
             "metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -190,24 +239,54 @@ def main():
                        "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"]},
                        "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"]},
         }
-        if search_launches:
-            avg_ms = search_ms / search_launches
-            pairs_per_launch = pairs_total / search_launches
-            exec_tflops = pairs_per_launch * EXEC_FLOPS_PER_PAIR / (avg_ms * 1e-3) / 1e12
-            algo = algorithmic_flops(scene, shader, cam, stats) * args.steps / search_launches
-            algo_tflops = algo / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {
-                "bound": "valu_fp32", "kernel": "k_search", "achieved": round(exec_tflops, 2), "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(exec_tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                "launches_per_frame": search_launches // args.steps, "avg_launch_ms": round(avg_ms, 4),
-                "pairs_per_launch": pairs_per_launch, "flops_per_pair_executed": EXEC_FLOPS_PER_PAIR,
-                "search_share_of_frame": round(search_ms / (dt * 1e3), 4),
-                "reference_formula_equivalent": {"tflops": round(algo_tflops, 2),
-                                                 "frac_of_peak": round(algo_tflops / PEAK_FP32_TFLOPS, 4),
-                                                 "flops_per_test": ALGO_FLOPS},
-            }
+        kernels = {"search_ms_per_frame": round(acc["search_ms"] / args.steps, 4),
+                   "resolve_ms_per_frame": round(acc["resolve_ms"] / args.steps, 4),
+                   "frame_ms": round(ms_per_step, 4)}
+        out["kernel_time"] = kernels
+        if acc["search_launches"] == 0:
+            # fewer than 64 primitives: no search at all, the frame is the fp64 resolve kernels
+            rb = resolve_bytes(stats, n_rays_padded, len(shader.lights), w, h)
+            avg_ms = acc["resolve_ms"] / acc["resolve_launches"]
+            gbs = rb * args.steps / acc["resolve_launches"] / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_resolve_primary + k_light_resolve (fp64 brute force)",
+                               "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
+        elif args.mode == "allpairs":
+            out["roofline"] = valu_roofline(acc, stats, args.steps)
+        elif acc["resolve_ms"] >= acc["search_ms"]:
+            rb = resolve_bytes(stats, n_rays_padded, len(shader.lights), w, h)
+            avg_ms = acc["resolve_ms"] / acc["resolve_launches"]
+            gbs = rb * args.steps / acc["resolve_launches"] / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_light_resolve (+ k_resolve_primary)",
+                               "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                               "launches_per_frame": acc["resolve_launches"] // args.steps,
+                               "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": rb}
         else:
-            out["roofline"] = None
+            # packet search: every workgroup of 1024 rays streams the whole cone table from L2 once
+            n_prims_padded = (scene.n_primitives + 511) // 512 * 512
+            groups = n_rays_padded / 1024 + stats["shadow_rays"] / 1024.0
+            tb = groups * n_prims_padded * 20.0 + (stats["primary_rays"] + stats["shadow_rays"]) * 20.0
+            avg_ms = acc["search_ms"] / acc["search_launches"]
+            gbs = tb * args.steps / acc["search_launches"] / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "l2", "kernel": "k_search_packet", "achieved": round(gbs, 1),
+                               "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_L2_GBS, 4),
+                               "traffic": None, "launches_per_frame": acc["search_launches"] // args.steps,
+                               "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": tb,
+                               "note": "table bytes are served by L2 (the table fits), not HBM"}
+        if world == 1 and args.mode == "packet" and not args.no_allpairs and acc["search_launches"]:
+            o2 = B.opts(w, h, mode=B.MODE_ALLPAIRS)
+            k2 = max(1, min(args.steps, 3))
+            run_frames(r, cam, shader, o2, fb, stream, 1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            acc2, stats2 = run_frames(r, cam, shader, o2, fb, stream, k2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            out["all_pairs"] = {"value": round(rays_step * k2 / dt2 / 1e6, 2), "unit": "Mrays/s", "steps": k2,
+                                "ms_per_step": round(dt2 * 1e3 / k2, 4),
+                                "search_ms_per_frame": round(acc2["search_ms"] / k2, 4),
+                                "roofline": valu_roofline(acc2, stats2, k2)}
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             stride = args.cpu_stride

@@ -114,10 +114,12 @@ typedef struct rt355_shader {
 } rt355_shader;
 
 /* ---- render options ------------------------------------------------------------------ */
-#define RT355_MODE_FAST  0 /* fp32 conservative candidate search + fp64 exact evaluation   */
-#define RT355_MODE_BRUTE 1 /* fp64 exact evaluation of every ray/primitive pair (debug)   */
-#define RT355_MODE_PACKET 2 /* as FAST, but each wave first culls the primitives against the
-                               beam of its 256 neighbouring rays; same candidates, same frame  */
+/* All three modes produce the same frame, byte for byte; they differ in how the ray/primitive
+ * pairs that the fp64 reference formulas must evaluate are found. */
+#define RT355_MODE_ALLPAIRS 0 /* fp32 conservative test of EVERY ray/primitive pair (FP32-VALU bound) */
+#define RT355_MODE_BRUTE    1 /* fp64 formulas on every pair, no search (debug / tiny scenes)         */
+#define RT355_MODE_PACKET   2 /* as ALLPAIRS, but a workgroup first culls the primitive table against
+                                 the beam of its 1024 neighbouring rays; the default of the hosts     */
 
 typedef struct rt355_opts {
     int32_t width, height; /* the reference's globals (main.cpp:33)                         */
@@ -134,7 +136,8 @@ typedef struct rt355_stats {
     uint64_t exact_tests;    /* pairs evaluated by the fp64 reference formulas              */
     uint64_t overflow_rays;  /* rays whose candidate list overflowed (re-done brute force)  */
     double   ms_device;      /* HIP-event time of the device work of this call              */
-    uint64_t packet_survivors; /* RT355_MODE_PACKET: (wave, primitive) pairs that passed the beam test */
+    uint64_t packet_survivors; /* RT355_MODE_PACKET: (wave, primitive) pairs that passed both beam tests */
+    uint64_t primary_hits;   /* camera rays that hit something                              */
 } rt355_stats;
 
 typedef struct rt355_scene rt355_scene; /* opaque, library-owned, bound to one HIP device */
@@ -164,9 +167,11 @@ int rt355_render_device(rt355_scene *scene, const rt355_camera *cam,
 /* Wait for the scene's outstanding render and fill the stats passed to it. */
 int rt355_scene_sync(rt355_scene *scene);
 
-/* Average HIP-event duration (ms) of the candidate-search kernel launches of the last
- * synced render, and their count.  Used by the benchmark's roofline figure. */
+/* Summed HIP-event duration (ms) of the candidate-search kernel launches of the last synced
+ * render, and their count.  Used by the benchmark's roofline figure. */
 int rt355_scene_search_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *launches);
+/* Same for the fp64 resolve kernels (k_resolve_primary + one k_light_resolve per light). */
+int rt355_scene_resolve_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *launches);
 
 /* Debug probe: objs[obj]->CalcIntersect(View(pe,npe)) for n host rays (n x 6 doubles: pe, npe)
  * evaluated by the device's fp64 formulas; out = n x 9 doubles (t, ph[3], nh[3], uv[2]; t = -1

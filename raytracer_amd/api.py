@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from .binding import ERR, MODE_FAST, CStats, COpts, PackedScene, Scene, Shader, opts as make_opts
+from .binding import ERR, MODE_PACKET, CStats, COpts, PackedScene, Scene, Shader, opts as make_opts
 
 _LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt355.so")
 _lib = None
@@ -37,6 +37,7 @@ def lib():
         L.rt355_render_device.argtypes = [C.c_void_p] * 7
         L.rt355_scene_sync.argtypes = [C.c_void_p]
         L.rt355_scene_search_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.rt355_scene_resolve_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.rt355_scene_search_launch_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
         L.rt355_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
@@ -70,7 +71,7 @@ class Renderer:
             pass
 
     def render(self, cam, shader: Shader, width: int, height: int, alias=0, row_begin=0, row_end=0,
-               mode=MODE_FAST, out: np.ndarray | None = None):
+               mode=MODE_PACKET, out: np.ndarray | None = None):
         """Host framebuffer path (rt355_render).  Returns (pixmap (H,W,3) uint8, stats dict)."""
         o = make_opts(width, height, alias, row_begin, row_end, mode)
         if out is None:
@@ -93,6 +94,11 @@ class Renderer:
     def search_kernel_ms(self):
         ms, n = C.c_double(), C.c_int32()
         _check(lib().rt355_scene_search_kernel_ms(self.handle, C.byref(ms), C.byref(n)), "search_kernel_ms")
+        return ms.value, n.value
+
+    def resolve_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int32()
+        _check(lib().rt355_scene_resolve_kernel_ms(self.handle, C.byref(ms), C.byref(n)), "resolve_kernel_ms")
         return ms.value, n.value
 
     def search_launch_ms(self):

@@ -15,7 +15,7 @@ from typing import List, Sequence
 import numpy as np
 
 OBJ_PLANE, OBJ_SPHERE, OBJ_MESH = 0, 1, 2
-MODE_FAST, MODE_BRUTE, MODE_PACKET = 0, 1, 2
+MODE_ALLPAIRS, MODE_BRUTE, MODE_PACKET = 0, 1, 2
 
 ERR = {0: "OK", -1: "ERR_ARG", -2: "ERR_UNSUPPORTED", -3: "ERR_DEVICE", -4: "ERR_NOMEM"}
 
@@ -70,14 +70,14 @@ class COpts(C.Structure):
 class CStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("pair_tests", C.c_uint64), ("exact_tests", C.c_uint64),
-                ("overflow_rays", C.c_uint64), ("ms_device", C.c_double), ("packet_survivors", C.c_uint64)]
+                ("overflow_rays", C.c_uint64), ("ms_device", C.c_double), ("packet_survivors", C.c_uint64), ("primary_hits", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 assert C.sizeof(CTexture) == 32 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
-assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 24 and C.sizeof(CStats) == 56
+assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 24 and C.sizeof(CStats) == 64
 
 
 def _normalize(v: Sequence[float]):
@@ -240,7 +240,7 @@ def camera(p_eye=(0, -20, 0), v_view=(0, 1, 0), v_up=(0, 0, 1), dist=10.0, width
     return c
 
 
-def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_FAST) -> COpts:
+def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_PACKET) -> COpts:
     return COpts(width, height, alias, row_begin, row_end, mode)
 
 

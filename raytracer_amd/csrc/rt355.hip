@@ -855,10 +855,10 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *
     if (lane == 0 && n_surv) {
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
 #ifdef RT355_DEBUG_SURVIVORS
-        atomicMax(&counters[4], (unsigned long long)n_surv);
-        if (n_surv > 256) atomicAdd(&counters[5], 1ull);
-        if (n_surv > 1024) atomicAdd(&counters[6], 1ull);
-        if (n_surv > 4096) atomicAdd(&counters[7], 1ull);
+        atomicMax(&counters[8], (unsigned long long)n_surv);
+        if (n_surv > 256) atomicAdd(&counters[9], 1ull);
+        if (n_surv > 1024) atomicAdd(&counters[10], 1ull);
+        if (n_surv > 4096) atomicAdd(&counters[11], 1ull);
 #endif
     }
 }
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
                                                          int brute, Bundle next,
                                                          unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_shadow = 0, n_eval = 0, n_over = 0, bin = 0xffffffffu;
+    uint32_t n_shadow = 0, n_eval = 0, n_over = 0, n_hit = 0, bin = 0xffffffffu;
     do {
     if (rid >= f.n_rays) break;
     int x, y;
@@ -970,6 +970,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     if (sh.n_lights == 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
         w.rec_obj[rid] = obj;
         store_pixel(pixmap, f, x, y, 0u);
+        n_hit = 1;
         break;
     }
     const size_t n = f.n_rays;
@@ -981,7 +982,9 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_cm1[rid] = cm1;
     w.rec_sum[rid] = 0u;
     n_shadow = light_prepare(sh, 0, next, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w, bin);
+    n_hit = 1;
     } while (0);
+    wave_count(w.counters, 4, n_hit);
     if (next.binned) { // all lanes of the wave arrive here
         const uint32_t rank = wave_bin_rank(w.bin_hist, bin, bin != 0xffffffffu);
         if (rid < f.n_rays) { w.bin_id[rid] = bin; w.bin_rank[rid] = rank; }
@@ -1132,6 +1135,9 @@ struct rt355_scene {
     // timing / stats of the outstanding render
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_search; // begin/end pairs
+    std::vector<hipEvent_t> ev_resolve; // begin/end pairs
+    int resolve_launches = 0;
+    double resolve_ms = 0;
     int search_launches = 0;
     double search_ms = 0;
     std::vector<double> launch_ms;
@@ -1270,6 +1276,7 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
     for (hipEvent_t e : sc->ev_search) (void)hipEventDestroy(e);
+    for (hipEvent_t e : sc->ev_resolve) (void)hipEventDestroy(e);
     delete sc;
 }
 
@@ -1283,6 +1290,8 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         sc->ev_search.push_back(e);
+        HIP_TRY(hipEventCreate(&e));
+        sc->ev_resolve.push_back(e);
     }
     if (n_rays <= sc->work_rays) return RT355_OK;
     free_work(sc);
@@ -1330,7 +1339,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     int y0 = opts->row_begin, y1 = opts->row_end;
     if (y0 == 0 && y1 == 0) y1 = opts->height;
     if (y0 < 0 || y1 > opts->height || y0 >= y1) return fail(RT355_ERR_ARG, "row slab out of range");
-    if (opts->mode != RT355_MODE_FAST && opts->mode != RT355_MODE_BRUTE && opts->mode != RT355_MODE_PACKET)
+    if (opts->mode != RT355_MODE_ALLPAIRS && opts->mode != RT355_MODE_BRUTE && opts->mode != RT355_MODE_PACKET)
         return fail(RT355_ERR_ARG, "unknown mode");
     HIP_TRY(hipSetDevice(sc->device));
     if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
@@ -1454,13 +1463,17 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         return RT355_OK;
     };
     if ((rc = clear_bins(bundles[1]))) return rc;
+    HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
     hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work,
                        bundles[0].kind ? 0 : 1, bundles[1], pix);
+    HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
     for (int k = 0; k < nl; k++) {
         if (bundles[1 + k].kind && (rc = run_search(1 + k))) return rc;
         if ((rc = clear_bins(bundles[2 + k]))) return rc;
+        HIP_TRY(hipEventRecord(sc->ev_resolve[2 + 2 * k], st));
         hipLaunchKernelGGL(k_light_resolve, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work, k,
                            bundles[1 + k].kind ? 0 : 1, bundles[2 + k], pix);
+        HIP_TRY(hipEventRecord(sc->ev_resolve[3 + 2 * k], st));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, st));
@@ -1470,6 +1483,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     sc->pending_primary = (uint64_t)f.width * f.rows;
     sc->pending_nprims = sc->view.n_prims;
     sc->search_launches = launches;
+    sc->resolve_launches = 1 + nl;
     return RT355_OK;
 }
 
@@ -1479,10 +1493,10 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     HIP_TRY(hipSetDevice(sc->device));
     HIP_TRY(hipEventSynchronize(sc->ev_end));
     sc->pending = false;
-    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[4] = {0, 0, 0, 0};
+    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(shards, sc->work.counters, sizeof shards, hipMemcpyDeviceToHost));
     for (int i = 0; i < COUNTER_SHARDS; i++)
-        for (int j = 0; j < 4; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
+        for (int j = 0; j < 5; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
     sc->search_ms = 0;
@@ -1493,6 +1507,12 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         sc->search_ms += m;
         sc->launch_ms[i] = m;
     }
+    sc->resolve_ms = 0;
+    for (int i = 0; i < sc->resolve_launches; i++) {
+        float m = 0;
+        HIP_TRY(hipEventElapsedTime(&m, sc->ev_resolve[2 * i], sc->ev_resolve[2 * i + 1]));
+        sc->resolve_ms += m;
+    }
     if (sc->pending_stats) {
         rt355_stats *s = sc->pending_stats;
         s->primary_rays = sc->pending_primary;
@@ -1502,8 +1522,9 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->pair_tests = (sc->pending_primary + ctr[0]) * (uint64_t)sc->pending_nprims;
         s->ms_device = ms;
         s->packet_survivors = ctr[3];
+        s->primary_hits = ctr[4];
 #ifdef RT355_DEBUG_SURVIVORS
-        fprintf(stderr, "[rt355] survivors: total %llu max/wave %llu waves>256 %llu >1024 %llu >4096 %llu\n", ctr[3], shards[4], shards[5], shards[6], shards[7]);
+        fprintf(stderr, "[rt355] survivors: total %llu max/wave %llu waves>256 %llu >1024 %llu >4096 %llu\n", ctr[3], shards[8], shards[9], shards[10], shards[11]);
 #endif
     }
     return RT355_OK;
@@ -1524,6 +1545,13 @@ extern "C" int rt355_debug_set_times_buffer(void *dptr) {
     return RT355_OK;
 }
 #endif
+
+extern "C" int rt355_scene_resolve_kernel_ms(rt355_scene *sc, double *ms_sum, int32_t *launches) {
+    if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
+    *ms_sum = sc->resolve_ms;
+    *launches = sc->resolve_launches;
+    return RT355_OK;
+}
 
 extern "C" int rt355_scene_search_launch_ms(rt355_scene *sc, int32_t index, double *ms) {
     if (!sc || !ms || index < 0 || index >= (int32_t)sc->launch_ms.size()) return fail(RT355_ERR_ARG, "bad launch index");

@@ -181,7 +181,7 @@ inline rt355_stats setPixels(DeviceScene &dev, const Scene &sce, const Shader &s
     detail::put(s.border, shd.border_color);
     rt355_opts o; std::memset(&o, 0, sizeof o);
     o.width = width; o.height = height; o.alias = alias; o.row_begin = row_begin; o.row_end = row_end;
-    o.mode = RT355_MODE_FAST;
+    o.mode = RT355_MODE_PACKET;
     rt355_stats st; std::memset(&st, 0, sizeof st);
     detail::check(rt355_render(dev.handle(), &c, &s, &o, pixmap, &st), "rt355_render");
     return st;

@@ -39,7 +39,7 @@ def _compare(got, want, exact=True):
         assert int(np.abs(diff).max()) <= 1
 
 
-@pytest.mark.parametrize("mode", [B.MODE_FAST, B.MODE_BRUTE, B.MODE_PACKET])
+@pytest.mark.parametrize("mode", [B.MODE_ALLPAIRS, B.MODE_BRUTE, B.MODE_PACKET])
 @pytest.mark.parametrize("name", S.SMALL_CASES)
 def test_small_cases_vs_golden(api, golden_dir, name, mode):
     gold = np.load(os.path.join(golden_dir, f"frame_{name}.npy"))
@@ -93,7 +93,7 @@ def test_mid_size_scenes_vs_checker(api, oracle):
         cam = S.default_camera(w, h)
         want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
         r = api.Renderer(sc)
-        got, st = r.render(cam, sh, w, h)
+        got, st = r.render(cam, sh, w, h, mode=B.MODE_ALLPAIRS)
         brute, _ = r.render(cam, sh, w, h, mode=B.MODE_BRUTE)
         packet, pst = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
         r.close()
@@ -245,7 +245,7 @@ def test_random_scenes_search_is_conservative(api, oracle, seed):
     assert sc.n_primitives >= 64
     want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
     r = api.Renderer(sc)
-    got, st = r.render(cam, sh, w, h)
+    got, st = r.render(cam, sh, w, h, mode=B.MODE_ALLPAIRS)
     packet, pst = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
     r.close()
     _compare(got, want)

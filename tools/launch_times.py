@@ -8,7 +8,7 @@ from raytracer_amd import binding as B
 from raytracer_amd.api import Renderer
 
 wl = sys.argv[1]
-mode = {"fast": B.MODE_FAST, "packet": B.MODE_PACKET}[sys.argv[2]]
+mode = {"allpairs": B.MODE_ALLPAIRS, "fast": B.MODE_ALLPAIRS, "packet": B.MODE_PACKET}[sys.argv[2]]
 scene, shader, cam, w, h = build_workload(wl)
 r = Renderer(scene)
 fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
