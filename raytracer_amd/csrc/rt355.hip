@@ -1,15 +1,17 @@
 // rt355.hip -- kernels and C ABI of the MI355X renderer (gfx950 only).
 //
-// Frame pipeline (all on one HIP stream, one launch each):
-//   k_bundle_origin   per (ray bundle, primitive): fp32 bounding cone + edge-plane tables
+// Frame pipeline (all on one HIP stream):
 //   k_gen_primary     camera rays (CalcView, main.cpp:269-276) -> fp32 directions
-//   k_search          THE HOT KERNEL: every ray of a bundle against every primitive, fp32,
+//   k_bundle_origin / k_bundle_direction   per (ray bundle, primitive): fp32 bounding cone or
+//                     circle + edge tables
+//   k_search_packet / k_search   THE SEARCH: rays of a bundle against the primitive table, fp32,
 //                     conservative (no false negatives) -> per-ray candidate lists
-//   k_resolve_primary fp64 reference formulas on the candidates -> closest hit, texture
-//                     lookup, pre-shadow colour of light 0
-//   k_search          (per light: shadow rays seen from the light position)
-//   k_light_resolve   fp64 closest occluder on the candidates -> CalcShadow, running mean,
-//                     next light's pre-shadow colour or the final RGB8 store
+//   k_resolve_primary fp64 reference formulas on the candidates -> closest hit, texture lookup,
+//                     hit record, and the shadow rays of the first group of lights
+//   (per light of the group: bundle table, direction sort, search -- one workspace slot each)
+//   k_shade_group     per hit and light of the group: fp64 closest occluder on the candidates,
+//                     diffuse / specular / border / CalcShadow, running mean; then the next
+//                     group's shadow rays or the final RGB8 store
 //
 // A "bundle" is a set of rays with a common origin: the camera rays (origin = eye) or the
 // shadow rays of one point/spot/area light traced backwards (origin = light position).  For
@@ -74,22 +76,26 @@ struct Frame {
     uint32_t n_rays;                        // padded: tiles * 1024
 };
 
+#define LIGHT_GROUP 8 // lights whose shadow rays and candidates are in flight together
 struct Work { // per-ray buffers, all indexed by rid (SoA)
-    double *rec_d;      // [9][n]: ph.xyz, nh.xyz, npe.xyz of the primary hit
+    double *rec_d;      // [10][n]: ph.xyz, nh.xyz, reh.xyz (view direction mirrored at the hit), border weight
     int32_t *rec_obj;   // object index of the hit, -1 miss, -2 outside the frame
     uint32_t *rec_cm0;  // material colour | no_border << 24
     uint32_t *rec_cm1;  // dark colour
-    uint32_t *rec_sum;  // clr_sum of Shader::shading
-    uint32_t *rec_pre;  // colour before CalcShadow | needs_shadow_ray << 24
-    float4 *ray32;      // fp32 search direction of the current bundle (NaN = inactive)
-    uint32_t *cand_cnt; // candidates found for the current bundle
-    uint32_t *cand;     // [CAND_CAP][n]
-    unsigned long long *counters; // 0 shadow rays, 1 candidates evaluated, 2 overflow rays
-    uint32_t *tile_count; // [tiles + 1] active rays per tile, then exclusive offsets; last = total
-    uint32_t *active_rid; // [n] rids of the current bundle's active rays, tile-major order kept
+    uint32_t *rec_sum;  // clr_sum of Shader::shading, carried from one group of lights to the next
+    unsigned long long *counters; // 0 shadow rays, 1 candidates evaluated, 2 overflow rays, 3 packet survivors, 4 hits
+    // One slot per bundle in flight: slot g serves light k0 + g of the current group (slot 0 first
+    // serves the camera rays).  Every array below is [slots][its stride].
+    uint32_t n;           // rays per slot (= Frame::n_rays)
+    float4 *ray32;        // [n] fp32 search record of the slot's rays (NaN = inactive)
+    uint32_t *cand_cnt;   // [n] candidates found
+    uint32_t *cand;       // [CAND_CAP][n]
+    uint32_t *tile_count; // [tile_stride] active rays per tile, then exclusive offsets; entry [tiles] = total
+    uint32_t *active_rid; // [list_stride] rids of the slot's active rays, tile-major or direction-sorted
     uint32_t *bin_hist;   // [RT_BINS + 2] packet search: rays per direction bin, then offsets
     uint32_t *bin_id;     // [n] packet search: direction bin of each ray, 0xffffffff = inactive
     uint32_t *bin_rank;   // [n] packet search: rank of the ray inside its bin
+    uint32_t tile_stride, list_stride;
 };
 
 // Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
@@ -207,6 +213,10 @@ struct Bundle {
     float plane_extent; // kind 2: half-width of the binning grid on the projection plane
 };
 #define RT_EPS22 2.384185791015625e-07 /* 2^-22 */
+struct Group { // lights k0 .. k0 + count - 1 and the bundles of their shadow rays (slot g = light k0 + g)
+    int k0, count;
+    Bundle b[LIGHT_GROUP];
+};
 
 __global__ void k_bundle_direction(SceneView s, Bundle bd, d3 w, int n_padded, float4 *__restrict__ L1,
                                    float4 *__restrict__ L2) {
@@ -437,11 +447,12 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict_
 }
 
 // Offsets of the direction bins, with every run of 16 consecutive bins (a 4x4 patch of cells on
-// the Hilbert curve) padded to a multiple of 256 rays, so that no wave of the packet search
+// the Hilbert curve) padded to a multiple of 256 rays (the padding entries of the sorted list are
+// written here), so that no wave of the packet search
 // mixes rays of different patches: a wave's beam is never wider than one patch, whatever the ray
 // density.  One workgroup; thread c owns patch c.  hist[RT_BINS + 1] receives the padded total.
 #define RT_PATCH 16
-__global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist) {
+__global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist, uint32_t *__restrict__ active_rid) {
     __shared__ uint32_t part[1024];
     const int c = threadIdx.x;
     uint4 v[RT_PATCH / 4];
@@ -459,6 +470,7 @@ __global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist)
         __syncthreads();
     }
     uint32_t run = part[c] - padded;
+    for (uint32_t i = run + sum; i < run + padded; i++) active_rid[i] = 0xffffffffu; // padding = no ray
     uint4 *dst = (uint4 *)(hist + (size_t)c * RT_PATCH);
 #pragma unroll
     for (int i = 0; i < RT_PATCH / 4; i++) {
@@ -899,37 +911,48 @@ __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, 
     pixmap[i] = (unsigned char)cr(clr); pixmap[i + 1] = (unsigned char)cg(clr); pixmap[i + 2] = (unsigned char)cb(clr);
 }
 
-// Colour of light k before CalcShadow (shader.h:75-89) and the shadow ray it needs.
-__device__ __forceinline__ uint32_t light_prepare(const ShaderView &sh, int k, const Bundle &bd, d3 pe, d3 ph, d3 nh,
-                                              d3 npe, uint32_t cm0, uint32_t cm1, bool no_border, uint32_t rid,
-                                              const Work &w, uint32_t &bin) {
-    const DLight &L = sh.lights[k];
-    d3 nhl = light_nhl(L, ph);
-    uint32_t clr = calc_diffuse(L, cm0, cm1, nh, nhl);
-    clr = calc_specular(sh, L, clr, nh, npe, nhl);
-    if (!no_border) clr = calc_border(sh, clr, pe, ph, nh);
-    bool needs = !(dot(nh, vmul(nhl, -1)) <= 0); // shader.h:396
-    w.rec_pre[rid] = clr | (needs ? (1u << 24) : 0u);
-    if (bd.kind) {
-        float4 q = needs ? bundle_ray(bd, ph, nhl) : nan4();
-        w.ray32[rid] = q;
-        if (bd.binned && needs) bin = ray_bin(bd.kind, q, bd.plane_extent);
+// Shadow rays of one group of lights for a primary hit (shader.h:395-404): the fp32 search record of
+// each ray goes to the light's slot, and rays of binned bundles are counted into direction bins.
+// Called by all lanes of a wave; returns the number of shadow rays this lane's hit needs.
+__device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const Group &gr, const Work &w,
+                                                     uint32_t rid, bool in_range, bool hit, d3 ph, d3 nh) {
+    uint32_t n_shadow = 0;
+    for (int g = 0; g < gr.count; g++) {
+        const Bundle &bd = gr.b[g];
+        const size_t at = (size_t)g * w.n + rid;
+        uint32_t bin = 0xffffffffu;
+        if (hit) {
+            d3 nhl = light_nhl(sh.lights[gr.k0 + g], ph);
+            bool needs = !(dot(nh, vmul(nhl, -1)) <= 0); // shader.h:396
+            n_shadow += needs ? 1u : 0u;
+            if (bd.kind) {
+                float4 q = needs ? bundle_ray(bd, ph, nhl) : nan4();
+                if (needs || !bd.binned) w.ray32[at] = q;
+                if (bd.binned && needs) bin = ray_bin(bd.kind, q, bd.plane_extent);
+            }
+        } else if (in_range && bd.kind && !bd.binned) {
+            w.ray32[at] = nan4();
+        }
+        if (bd.binned) {
+            const uint32_t rank = wave_bin_rank(w.bin_hist + (size_t)g * (RT_BINS + 2), bin, bin != 0xffffffffu);
+            if (in_range) { w.bin_id[at] = bin; w.bin_rank[at] = rank; }
+        }
     }
-    return needs ? 1u : 0u;
+    return n_shadow;
 }
 
 __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
-                                                         int brute, Bundle next,
+                                                         int brute, Group first,
                                                          unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_shadow = 0, n_eval = 0, n_over = 0, n_hit = 0, bin = 0xffffffffu;
+    uint32_t n_eval = 0, n_over = 0, n_hit = 0;
+    d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
     do {
     if (rid >= f.n_rays) break;
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (!(x < f.width && y < f.rows)) {
         w.rec_obj[rid] = -2;
-        if (next.kind) w.ray32[rid] = nan4();
         break;
     }
     Ray e = calc_view(cam, (double)x / (double)f.width, (double)(y + f.row_begin) / (double)f.height);
@@ -937,14 +960,13 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
         w.rec_obj[rid] = -1;
-        if (next.kind) w.ray32[rid] = nan4();
         if (sh.n_lights == 0) store_pixel(pixmap, f, x, y, 0u);
         break;
     }
     // the accepted hit, in full (main.cpp:69-77)
     int obj = s.prim_obj[c.prim_best], tri = s.prim_tri[c.prim_best];
     const DObject &o = s.objects[obj];
-    d3 ph, nh; double uvx = 0, uvy = 0;
+    double uvx = 0, uvy = 0;
     if (tri >= 0) {
         const DTriangle &T = s.tris[tri];
         int outside; double u, v;
@@ -967,44 +989,42 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     uint32_t cm0 = o.rgb, cm1 = sh.ambient;
     if (o.texture_type == 1) texture_mapping(s, o, ph, uvx, uvy, &cm0, &cm1); // shader.h:53-58
     bool no_border = (o.type != RT_OBJ_SPHERE);                    // main.cpp:74
+    w.rec_obj[rid] = obj;
+    n_hit = 1;
     if (sh.n_lights == 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
-        w.rec_obj[rid] = obj;
         store_pixel(pixmap, f, x, y, 0u);
-        n_hit = 1;
         break;
     }
+    // what every light needs of this hit: reh and the border weight do not depend on the light
     const size_t n = f.n_rays;
+    const d3 reh = mirror_dir(nh, e.npe);
     w.rec_d[0 * n + rid] = ph.x; w.rec_d[1 * n + rid] = ph.y; w.rec_d[2 * n + rid] = ph.z;
     w.rec_d[3 * n + rid] = nh.x; w.rec_d[4 * n + rid] = nh.y; w.rec_d[5 * n + rid] = nh.z;
-    w.rec_d[6 * n + rid] = e.npe.x; w.rec_d[7 * n + rid] = e.npe.y; w.rec_d[8 * n + rid] = e.npe.z;
-    w.rec_obj[rid] = obj;
+    w.rec_d[6 * n + rid] = reh.x; w.rec_d[7 * n + rid] = reh.y; w.rec_d[8 * n + rid] = reh.z;
+    if (!no_border) w.rec_d[9 * n + rid] = border_weight(e.pe, ph, nh);
     w.rec_cm0[rid] = cm0 | (no_border ? (1u << 24) : 0u);
     w.rec_cm1[rid] = cm1;
-    w.rec_sum[rid] = 0u;
-    n_shadow = light_prepare(sh, 0, next, e.pe, ph, nh, e.npe, cm0, cm1, no_border, rid, w, bin);
-    n_hit = 1;
     } while (0);
+    const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, n_hit && sh.n_lights, ph, nh);
     wave_count(w.counters, 4, n_hit);
-    if (next.binned) { // all lanes of the wave arrive here
-        const uint32_t rank = wave_bin_rank(w.bin_hist, bin, bin != 0xffffffffu);
-        if (rid < f.n_rays) { w.bin_id[rid] = bin; w.bin_rank[rid] = rank; }
-    }
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
 }
 
-// CalcShadow for light k (shader.h:393-433), the running mean (shader.h:93), then either the next
-// light's pre-shadow colour or the pixel store (main.cpp:367-369).
-__global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
-                                                       int k, int brute, Bundle next,
-                                                       unsigned char *__restrict__ pixmap) {
+// Shader::shading's loop over the lights (shader.h:60-94) for the lights of one group: colour before
+// the shadow (shader.h:75-89), CalcShadow on the light's candidates (shader.h:393-433), the running
+// mean (shader.h:93); then either the next group's shadow rays or the pixel store (main.cpp:367-369).
+__global__ __launch_bounds__(256) void k_shade_group(SceneView s, ShaderView sh, Frame f, Work w, Group cur,
+                                                     Group next, unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_shadow = 0, n_eval = 0, n_over = 0, bin = 0xffffffffu;
+    uint32_t n_eval = 0, n_over = 0;
+    const bool last = (cur.k0 + cur.count == sh.n_lights);
+    bool hit = false;
+    d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
     do {
     if (rid >= f.n_rays) break;
     int obj = w.rec_obj[rid];
-    const bool last = (k + 1 == sh.n_lights);
     if (obj == -2) break;
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
@@ -1013,38 +1033,43 @@ __global__ __launch_bounds__(256) void k_light_resolve(SceneView s, ShaderView s
         break;
     }
     const size_t n = f.n_rays;
-    d3 ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
-    const DLight &L = sh.lights[k];
-    d3 nhl = light_nhl(L, ph);
-    uint32_t pre = w.rec_pre[rid];
-    double shd = 1;
-    if (pre & (1u << 24)) {
-        Ray sr = mkview(ph, vmul(nhl, -1)); // shader.h:395,404
-        Closest c;
-        closest_hit(s, sr, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, c, n_eval, n_over);
-        double Ld = vlen(vsub(ld3(L.position), ph)); // shader.h:412
-        if (c.t_best > 0 && c.t_best < Ld) shd = c.t_best / Ld;
-    } else {
-        shd = 0.5; // shader.h:396-398
+    ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
+    nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+    const d3 reh = D3(w.rec_d[6 * n + rid], w.rec_d[7 * n + rid], w.rec_d[8 * n + rid]);
+    const uint32_t cm0w = w.rec_cm0[rid], cm0 = cm0w & 0xffffffu, cm1 = w.rec_cm1[rid];
+    const bool no_border = (cm0w >> 24) & 1u;
+    const double border_w = no_border ? 0.0 : w.rec_d[9 * n + rid];
+    uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u;
+    for (int g = 0; g < cur.count; g++) {
+        const int k = cur.k0 + g;
+        const DLight &L = sh.lights[k];
+        const d3 nhl = light_nhl(L, ph);
+        uint32_t clr = calc_diffuse(L, cm0, cm1, nh, nhl);
+        clr = calc_specular(sh, L, clr, reh, nhl);
+        if (!no_border) clr = calc_border(sh, clr, border_w);
+        double shd = 0.5; // shader.h:396-398
+        if (!(dot(nh, vmul(nhl, -1)) <= 0)) {
+            Ray sr = mkview(ph, vmul(nhl, -1)); // shader.h:395,404
+            Closest c;
+            closest_hit(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+                        w.cand_cnt + (size_t)g * n, c, n_eval, n_over);
+            double Ld = vlen(vsub(ld3(L.position), ph)); // shader.h:412
+            shd = (c.t_best > 0 && c.t_best < Ld) ? c.t_best / Ld : 1.0;
+        }
+        clr = shadow_mix(sh, L, clr, nhl, shd);
+        sum = light_mean(sum, clr, k);
     }
-    uint32_t clr = shadow_mix(sh, L, pre & 0xffffffu, nhl, shd);
-    uint32_t sum = light_mean(w.rec_sum[rid], clr, k);
     if (last) {
         store_pixel(pixmap, f, x, y, sum);
         break;
     }
     w.rec_sum[rid] = sum;
-    d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
-    d3 npe = D3(w.rec_d[6 * n + rid], w.rec_d[7 * n + rid], w.rec_d[8 * n + rid]);
-    uint32_t cm0 = w.rec_cm0[rid];
-    n_shadow = light_prepare(sh, k + 1, next, ld3(cam.p_eye), ph, nh, npe, cm0 & 0xffffffu,
-                             w.rec_cm1[rid], (cm0 >> 24) & 1u, rid, w, bin);
+    hit = true;
     } while (0);
-    if (next.binned) { // all lanes of the wave arrive here
-        const uint32_t rank = wave_bin_rank(w.bin_hist, bin, bin != 0xffffffffu);
-        if (rid < f.n_rays) { w.bin_id[rid] = bin; w.bin_rank[rid] = rank; }
+    if (!last) {
+        const uint32_t n_shadow = emit_shadow_rays(sh, next, w, rid, rid < f.n_rays, hit, ph, nh);
+        wave_count(w.counters, 0, n_shadow);
     }
-    wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
 }
@@ -1131,6 +1156,7 @@ struct rt355_scene {
     float *L1s = nullptr;
     Work work{};
     uint32_t work_rays = 0;
+    int work_slots = 0;
     DLight *d_lights = nullptr; int lights_cap = 0;
     // timing / stats of the outstanding render
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -1253,13 +1279,14 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
-    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.rec_pre, w.ray32, w.cand_cnt, w.cand,
+    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand,
                   w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
     w = Work{};
     w.counters = keep;
     sc->work_rays = 0;
+    sc->work_slots = 0;
 }
 
 extern "C" void rt355_scene_destroy(rt355_scene *sc) {
@@ -1280,7 +1307,17 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     delete sc;
 }
 
-static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
+// Bytes of workspace one slot needs per ray; the number of slots is cut down so that all of them stay
+// below SLOT_BUDGET_BYTES (a 3840x2160 frame with 8 lights in flight takes about 11 GB).
+#define SLOT_BYTES_PER_RAY (sizeof(float4) + (CAND_CAP + 4) * sizeof(uint32_t))
+#define SLOT_BUDGET_BYTES (96ull << 30)
+static int slots_for(uint32_t n_rays, int n_lights) {
+    int slots = std::max(1, std::min(n_lights, LIGHT_GROUP));
+    while (slots > 1 && (unsigned long long)slots * n_rays * SLOT_BYTES_PER_RAY > SLOT_BUDGET_BYTES) slots--;
+    return slots;
+}
+
+static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundles, int n_groups) {
     if (!sc->L1) {
         HIP_TRY(hipMalloc((void **)&sc->L1, (size_t)sc->n_padded * sizeof(float4)));
         HIP_TRY(hipMalloc((void **)&sc->L2, (size_t)sc->n_padded * 3 * sizeof(float4)));
@@ -1290,28 +1327,42 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int n_bundles) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         sc->ev_search.push_back(e);
+    }
+    while ((int)sc->ev_resolve.size() < 2 * (1 + n_groups)) {
+        hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         sc->ev_resolve.push_back(e);
     }
-    if (n_rays <= sc->work_rays) return RT355_OK;
-    free_work(sc);
     Work &w = sc->work;
-    size_t n = n_rays;
-    HIP_TRY(hipMalloc((void **)&w.rec_d, 9 * n * sizeof(double)));
+    if (n_rays <= sc->work_rays && slots <= sc->work_slots) {
+        // the slot strides follow the frame being rendered, not the capacity
+        w.n = n_rays;
+        w.tile_stride = n_rays / RAYS_PER_TILE + 1;
+        w.list_stride = n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS;
+        return RT355_OK;
+    }
+    const uint32_t cap_rays = std::max(n_rays, sc->work_rays);
+    const int cap_slots = std::max(slots, sc->work_slots);
+    free_work(sc);
+    const size_t n = cap_rays, g = (size_t)cap_slots;
+    HIP_TRY(hipMalloc((void **)&w.rec_d, 10 * n * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&w.rec_obj, n * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&w.rec_cm0, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.rec_cm1, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.rec_sum, n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.rec_pre, n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.ray32, n * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&w.cand_cnt, n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.cand, (size_t)CAND_CAP * n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.tile_count, (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.active_rid, (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.bin_hist, (RT_BINS + 2) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.bin_id, n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.bin_rank, n * sizeof(uint32_t)));
-    sc->work_rays = n_rays;
+    HIP_TRY(hipMalloc((void **)&w.ray32, g * n * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&w.cand_cnt, g * n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.cand, g * CAND_CAP * n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.tile_count, g * (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.bin_hist, g * (RT_BINS + 2) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.bin_id, g * n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.bin_rank, g * n * sizeof(uint32_t)));
+    sc->work_rays = cap_rays;
+    sc->work_slots = cap_slots;
+    w.n = n_rays;
+    w.tile_stride = n_rays / RAYS_PER_TILE + 1;
+    w.list_stride = n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS;
     return RT355_OK;
 }
 
@@ -1352,7 +1403,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     if (n_rays64 > 0x7fffffffull) return fail(RT355_ERR_ARG, "slab too large: split it into fewer rows per call");
     f.n_rays = (uint32_t)n_rays64;
     const int nl = shader->n_lights;
-    int rc = ensure_work(sc, f.n_rays, 1 + nl);
+    const int slots = slots_for(f.n_rays, nl);
+    const int n_groups = (nl + slots - 1) / slots;
+    int rc = ensure_work(sc, f.n_rays, slots, 1 + nl, n_groups);
     if (rc) return rc;
 
     // lights -> device
@@ -1418,62 +1471,81 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     const unsigned n_tiles = (unsigned)(f.tiles_x * f.tiles_y);
     unsigned char *pix = (unsigned char *)d_pixmap;
     int launches = 0;
-    auto run_search = [&](int bi) -> int {
+    const Work &w = sc->work;
+    // search of bundle bi (0 = camera rays, 1 + k = light k) in workspace slot g
+    auto run_search = [&](int bi, int g) -> int {
         const Bundle &b = bundles[bi];
         const bool is_eye = (bi == 0);
+        float4 *ray32 = w.ray32 + (size_t)g * w.n;
+        uint32_t *cand = w.cand + (size_t)g * CAND_CAP * w.n, *cand_cnt = w.cand_cnt + (size_t)g * w.n;
+        uint32_t *tile_count = w.tile_count + (size_t)g * w.tile_stride;
+        uint32_t *active_rid = w.active_rid + (size_t)g * w.list_stride;
+        uint32_t *bin_hist = w.bin_hist + (size_t)g * (RT_BINS + 2);
         if (b.kind == 1)
             hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, b.o, is_eye ? 1 : 0, sc->n_padded, sc->L1, sc->L2, sc->L1s);
         else
             hipLaunchKernelGGL(k_bundle_direction, dim3(setup_blocks), dim3(256), 0, st, sc->view, b, ray_dir[bi], sc->n_padded, sc->L1, sc->L2);
         const uint32_t *list = nullptr, *total = nullptr;
         if (b.binned) { // the producer of the rays counted them into direction bins: order them
-            hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, sc->work.bin_hist);
-            // padding slots of the sorted list stay 0xffffffff = no ray
-            HIP_TRY(hipMemsetAsync(sc->work.active_rid, 0xff, ((size_t)f.n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS) * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks), dim3(256), 0, st, sc->work.bin_id, sc->work.bin_rank, sc->work.bin_hist, sc->work.active_rid);
-            list = sc->work.active_rid; total = sc->work.bin_hist + RT_BINS + 1;
+            hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, bin_hist, active_rid);
+            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks), dim3(256), 0, st, w.bin_id + (size_t)g * w.n, w.bin_rank + (size_t)g * w.n, bin_hist, active_rid);
+            list = active_rid; total = bin_hist + RT_BINS + 1;
         } else if (!is_eye) { // shadow bundles are sparse: compact their active rays first
-            hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count);
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, sc->work.tile_count, (int)n_tiles);
-            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->work.ray32, sc->work.tile_count, sc->work.active_rid);
-            list = sc->work.active_rid; total = sc->work.tile_count + n_tiles;
+            hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, ray32, tile_count);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_count, (int)n_tiles);
+            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, ray32, tile_count, active_rid);
+            list = active_rid; total = tile_count + n_tiles;
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
-            const size_t n_slots = is_eye ? (size_t)f.n_rays : (size_t)f.n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS;
+            const size_t n_slots = is_eye ? (size_t)f.n_rays : (size_t)w.list_stride;
             const unsigned n_blocks = (unsigned)((n_slots + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
             if (b.kind == 1)
-                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt, w.counters);
             else
-                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt, sc->work.counters);
+                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt, w.counters);
         } else if (b.kind == 1)
-            hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
+            hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt);
         else
-            hipLaunchKernelGGL(k_search<2>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, sc->work.ray32, f.n_rays, list, total, sc->work.cand, sc->work.cand_cnt);
+            hipLaunchKernelGGL(k_search<2>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt);
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
         launches++;
         return RT355_OK;
     };
-    if (bundles[0].kind) {
-        hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, sc->work.ray32);
-        if ((rc = run_search(0))) return rc;
-    }
-    auto clear_bins = [&](const Bundle &nb) -> int { // the next kernel counts its rays into the bins
-        if (nb.binned) HIP_TRY(hipMemsetAsync(sc->work.bin_hist, 0, (RT_BINS + 2) * sizeof(uint32_t), st));
+    // the lights, in groups of `slots`
+    auto group_of = [&](int j) {
+        Group gr;
+        memset(&gr, 0, sizeof gr);
+        gr.k0 = j * slots;
+        gr.count = std::max(0, std::min(slots, nl - gr.k0));
+        for (int g = 0; g < gr.count; g++) gr.b[g] = bundles[1 + gr.k0 + g];
+        return gr;
+    };
+    auto clear_bins = [&](const Group &gr) -> int { // the next kernel counts the group's rays into the bins
+        bool any = false;
+        for (int g = 0; g < gr.count; g++) any = any || gr.b[g].binned;
+        if (any) HIP_TRY(hipMemsetAsync(w.bin_hist, 0, (size_t)gr.count * (RT_BINS + 2) * sizeof(uint32_t), st));
         return RT355_OK;
     };
-    if ((rc = clear_bins(bundles[1]))) return rc;
+    if (bundles[0].kind) {
+        hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, w.ray32);
+        if ((rc = run_search(0, 0))) return rc;
+    }
+    Group cur = group_of(0);
+    if ((rc = clear_bins(cur))) return rc;
     HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
-    hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work,
-                       bundles[0].kind ? 0 : 1, bundles[1], pix);
+    hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w,
+                       bundles[0].kind ? 0 : 1, cur, pix);
     HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
-    for (int k = 0; k < nl; k++) {
-        if (bundles[1 + k].kind && (rc = run_search(1 + k))) return rc;
-        if ((rc = clear_bins(bundles[2 + k]))) return rc;
-        HIP_TRY(hipEventRecord(sc->ev_resolve[2 + 2 * k], st));
-        hipLaunchKernelGGL(k_light_resolve, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, sc->work, k,
-                           bundles[1 + k].kind ? 0 : 1, bundles[2 + k], pix);
-        HIP_TRY(hipEventRecord(sc->ev_resolve[3 + 2 * k], st));
+    for (int j = 0; j < n_groups; j++) {
+        for (int g = 0; g < cur.count; g++)
+            if (cur.b[g].kind && (rc = run_search(1 + cur.k0 + g, g))) return rc;
+        Group next = group_of(j + 1);
+        if ((rc = clear_bins(next))) return rc;
+        HIP_TRY(hipEventRecord(sc->ev_resolve[2 + 2 * j], st));
+        hipLaunchKernelGGL(k_shade_group, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, f, w, cur, next, pix);
+        HIP_TRY(hipEventRecord(sc->ev_resolve[3 + 2 * j], st));
+        cur = next;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, st));
@@ -1483,7 +1555,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     sc->pending_primary = (uint64_t)f.width * f.rows;
     sc->pending_nprims = sc->view.n_prims;
     sc->search_launches = launches;
-    sc->resolve_launches = 1 + nl;
+    sc->resolve_launches = 1 + n_groups;
     return RT355_OK;
 }
 

@@ -269,6 +269,9 @@ __device__ __forceinline__ void texture_mapping(const SceneView &s, const DObjec
     }
 }
 
+#ifndef RT_POW25
+#define RT_POW25(x) pow25(x) /* -D'RT_POW25(x)=pow(x,25.0)' selects the library power */
+#endif
 // ---- shader.h -------------------------------------------------------------------------------------
 struct ShaderView {
     const DLight *lights;
@@ -291,22 +294,35 @@ __device__ __forceinline__ uint32_t calc_diffuse(const DLight &L, uint32_t cm0, 
     d3 lc = vmul(ld3(L.color), t);
     return cadd(cmulv(cm0, lc), cmulv(cm1, vsub(D3(1, 1, 1), lc)));
 }
+// x^25 for CalcSpecular's pow(s, 25) (shader.h:366): six multiplications, each rounded once, so the result
+// is within 3.5 ulp of the true power; its only use is a product with an 8-bit colour channel that is
+// truncated to an integer.
+__device__ __forceinline__ double pow25(double x) {
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+    return (x16 * x8) * x;
+}
+// reh of CalcSpecular (shader.h:352): the view direction mirrored at the surface; the same for every light
+__device__ __forceinline__ d3 mirror_dir(d3 nh, d3 npe) {
+    return normalize(vsub(npe, vmul(nh, 2 * dot(nh, npe))));
+}
 // CalcSpecular, shader.h:340-376 (SpecularType 0)
-__device__ __forceinline__ uint32_t calc_specular(const ShaderView &sh, const DLight &L, uint32_t clr, d3 nh,
-                                                  d3 npe, d3 nhl) {
-    d3 reh = normalize(vsub(npe, vmul(nh, 2 * dot(nh, npe))));
+__device__ __forceinline__ uint32_t calc_specular(const ShaderView &sh, const DLight &L, uint32_t clr, d3 reh,
+                                                  d3 nhl) {
     double s = dot(vmul(nhl, -1), reh);
     s = (s > 0) ? s : 0;
-    s = pow(s, 25.0);
+    s = RT_POW25(s);
     if (L.type == 2) s = s * spot_factor(L, nhl);
     return cadd(cmul(clr, 1 - s), cmul(sh.specular, s));
 }
-// CalcBorder, shader.h:378-387
-__device__ __forceinline__ uint32_t calc_border(const ShaderView &sh, uint32_t clr, d3 pe, d3 ph, d3 nh) {
+// b of CalcBorder (shader.h:378-385): the same for every light
+__device__ __forceinline__ double border_weight(d3 pe, d3 ph, d3 nh) {
     double b = 1 - dot(normalize(vsub(pe, ph)), nh);
     double mn = 0.8, mx = 0.9;
     b = (b - mn) / (mx - mn);
-    b = (b > 1) ? 1 : ((b < 0) ? 0 : b);
+    return (b > 1) ? 1 : ((b < 0) ? 0 : b);
+}
+// CalcBorder's blend, shader.h:386
+__device__ __forceinline__ uint32_t calc_border(const ShaderView &sh, uint32_t clr, double b) {
     return cadd(cmul(clr, 1 - b), cmul(sh.border, b));
 }
 // tail of CalcShadow, shader.h:412-432, given the closest occluder distance
@@ -315,7 +331,16 @@ __device__ __forceinline__ uint32_t shadow_mix(const ShaderView &sh, const DLigh
     if (L.type == 2) shd = shd * spot_factor(L, nhl);
     return cadd(cmul(clr, shd), cmul(sh.ambient, 1 - shd));
 }
-// running mean over lights, shader.h:93
+// running mean over lights, shader.h:93: clr_sum / (k+1) * k + clr / (k+1) on Color, i.e. per channel
+// trunc(c / (k+1)) with c an integer in 0..255 -- the correctly rounded double quotient truncates to the
+// integer quotient (a non-integer c/(k+1) is at least 1/(k+1) away from the next integer) -- then an exact
+// integer product taken mod 256.  The integer quotient is (c * M) >> 16 with M = 65536 / d + 1 for d <= 256.
 __device__ __forceinline__ uint32_t light_mean(uint32_t clr_sum, uint32_t clr, int k) {
-    return cadd(cmul(cdivd(clr_sum, (double)k + 1.0), (double)k), cdivd(clr, (double)k + 1.0));
+    const uint32_t d = (uint32_t)k + 1u;
+    const uint32_t M = (d <= 256u) ? (65536u / d + 1u) : 0u;
+    const uint32_t uk = (uint32_t)k;
+    const uint32_t r = (((cr(clr_sum) * M) >> 16) * uk + ((cr(clr) * M) >> 16)) & 0xffu;
+    const uint32_t g = (((cg(clr_sum) * M) >> 16) * uk + ((cg(clr) * M) >> 16)) & 0xffu;
+    const uint32_t bl = (((cb(clr_sum) * M) >> 16) * uk + ((cb(clr) * M) >> 16)) & 0xffu;
+    return RGB(r, g, bl);
 }

@@ -106,6 +106,25 @@ def test_mid_size_scenes_vs_checker(api, oracle):
         assert pst["exact_tests"] == st["exact_tests"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lights", [9, 19])
+def test_more_lights_than_one_group(api, oracle, n_lights):
+    """Lights are shaded in groups of at most 8; the running mean is carried from group to group."""
+    lights = S.ring_lights(n_lights)
+    lights[3] = S.light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 0.8, 0.6))
+    lights[8] = S.light_src(2, (0, 20, 90), (0.1, 0.5, -1), (1, 0.9, 0.8))
+    sh = S.Shader(lights, 0x101010, 0xDDDDDD, 0x202020)
+    for sc, (w, h) in ((S.spheres_scene(600, seed=11), (160, 96)), (S.default_scene(), (96, 64))):
+        cam = S.default_camera(w, h)
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+        r = api.Renderer(sc)
+        for mode in (B.MODE_PACKET, B.MODE_ALLPAIRS, B.MODE_BRUTE):
+            got, st = r.render(cam, sh, w, h, mode=mode)
+            _compare(got, want)
+            assert st["shadow_rays"] == wst["shadow_rays"]
+        r.close()
+
+
 def test_orbit_cameras_mesh(api, oracle):
     """Other view points (the camera sweep): eye bundle tables are rebuilt per frame."""
     sc = S.mesh_scene(2000, seed=3, tex_size=32)
