@@ -52,6 +52,14 @@
 #define PRIM_TILE 512       // primitives staged in LDS per step (8 KiB, double buffered)
 #endif
 #define CAND_CAP 32         // candidate slots per ray; overflowing rays fall back to brute force
+// a candidate is the primitive index plus the kind of exact test it needs (the search copies the
+// kind bits from .w of the primitive's first L2 row)
+#define CAND_SPHERE 0x40000000u
+#define CAND_TRI 0x80000000u
+#define CAND_INDEX 0x3fffffffu
+#ifndef CAND_BATCH
+#define CAND_BATCH 2        // candidates whose ids and records are loaded together by the exact tests
+#endif
 #define SEARCH_MIN_PRIMS 64 // below this the fp64 brute-force walk is cheaper than a search
 
 // ---- rid <-> pixel -------------------------------------------------------------------------------
@@ -120,6 +128,12 @@ __device__ __forceinline__ float4 nan4() {
 }
 
 // ---- bundle tables ---------------------------------------------------------------------------------
+// kind bits the search adds to a candidate's primitive index
+__device__ __forceinline__ uint32_t cand_kind(const SceneView &s, int i) {
+    if (i >= s.n_prims) return 0u;
+    if (s.prim_tri[i] >= 0) return CAND_TRI;
+    return (s.objects[s.prim_obj[i]].type == RT_OBJ_SPHERE) ? CAND_SPHERE : 0u;
+}
 // L1[i] = (ox, oy, oz, -thr): unit axis and negated cosine threshold of a cone, seen from the
 // bundle origin, that contains primitive i.  A ray with unit direction d can only hit i if
 // d . o - thr >= 0.  -thr = +2 marks "always a candidate" (planes, origin inside the sphere),
@@ -188,6 +202,7 @@ __global__ void k_bundle_origin(SceneView s, d3 O, int is_eye, int n_padded, flo
             }
         }
     }
+    a.w = __uint_as_float(cand_kind(s, i));
     L1[i] = l1;
     L1s[i] = sin_t;
     L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
@@ -271,6 +286,7 @@ __global__ void k_bundle_direction(SceneView s, Bundle bd, d3 w, int n_padded, f
             l1 = make_float4((float)uc, (float)vc, (float)(R * R * (1.0 + 1e-6)), (float)(R * (1.0 + 1e-6)));
         }
     }
+    a.w = __uint_as_float(cand_kind(s, i));
     L1[i] = l1;
     L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
 }
@@ -414,11 +430,13 @@ __device__ __forceinline__ uint32_t ray_bin(int kind, const float4 &q, float pla
 // Rays of a wave mostly fall into a few cells.  The wave first groups its lanes by cell with
 // ballots only (no memory traffic), then the first lane of every group adds the group's size to
 // the cell counter in ONE atomic instruction for the whole wave, and each lane's rank inside its
-// cell is the returned counter value plus its rank inside the group.  Must be called by all
-// lanes of the wave (inactive lanes pass false).  Returns the rank of the lane's ray in its cell.
-__device__ __forceinline__ uint32_t wave_bin_rank(uint32_t *__restrict__ hist, uint32_t bin, bool active) {
+// cell is the counter value returned to the group's first lane plus its rank inside the group.
+// Must be called by all lanes of the wave (inactive lanes pass false).
+__device__ __forceinline__ uint32_t wave_bin_count(uint32_t *__restrict__ hist, uint32_t bin, bool active,
+                                                   uint32_t &rank, uint32_t &leader_lane) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t leader_lane = lane, rank = 0, count = 0;
+    uint32_t count = 0;
+    leader_lane = lane; rank = 0;
     unsigned long long pending = __ballot(active);
     while (pending) {
         const int leader = __builtin_ctzll(pending);
@@ -433,8 +451,7 @@ __device__ __forceinline__ uint32_t wave_bin_rank(uint32_t *__restrict__ hist, u
     }
     uint32_t base = 0;
     if (active && lane == leader_lane) base = atomicAdd(&hist[bin], count);
-    base = (uint32_t)__shfl((int)base, (int)leader_lane, 64);
-    return base + rank;
+    return base; // valid in the group's first lane; the lane's rank in its cell is that value + rank
 }
 // position of every active ray in the direction-sorted list: start of its cell + rank in the cell
 __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id,
@@ -520,7 +537,7 @@ __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, co
         floor_ = -lin;
     }
     if (fminf(ea, fminf(eb, ec)) >= floor_) {
-        if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = prim;
+        if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = prim | __float_as_uint(a.w);
         cnt++;
     }
 }
@@ -844,7 +861,8 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *
                     }
                     if (any_hit) { // some ray is inside the cone / circle: pyramid / edge-function rows
                         float4 ea, eb, ec;
-                        ea.x = lane_bcast(ra.x, i); ea.y = lane_bcast(ra.y, i); ea.z = lane_bcast(ra.z, i); ea.w = 0.f;
+                        ea.x = lane_bcast(ra.x, i); ea.y = lane_bcast(ra.y, i); ea.z = lane_bcast(ra.z, i);
+                        ea.w = lane_bcast(ra.w, i); // the kind bits of the candidate id
                         eb.x = lane_bcast(rb.x, i); eb.y = lane_bcast(rb.y, i); eb.z = lane_bcast(rb.z, i); eb.w = 0.f;
                         ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
 #pragma unroll
@@ -894,11 +912,32 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
         }
         n = (uint32_t)s.n_prims;
     } else {
-        for (uint32_t k = 0; k < n; k++) {
-            int prim = (int)cand[(size_t)k * n_rays + rid];
-            int is_mesh, obj;
-            double t = prim_t(s, prim, e, &is_mesh, &obj);
-            c.visit(prim, obj, is_mesh, t);
+        // CAND_BATCH candidates at a time: first their ids, then their 32-byte records (independent
+        // loads, all in flight together), then the tests in list order
+        const uint32_t *cp = cand + rid;
+        for (uint32_t k0 = 0; k0 < n; k0 += CAND_BATCH) {
+            uint32_t id[CAND_BATCH];
+            double4 rec[CAND_BATCH];
+#pragma unroll
+            for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
+#pragma unroll
+            for (int j = 0; j < CAND_BATCH; j++) rec[j] = s.prim_rec[id[j] & CAND_INDEX];
+#pragma unroll
+            for (int j = 0; j < CAND_BATCH; j++) {
+                if (k0 + j >= n) break;
+                const int prim = (int)(id[j] & CAND_INDEX);
+                if (id[j] & CAND_SPHERE) {
+                    c.visit(prim, -2 - prim, 0, sphere_t_rec(rec[j], e));
+                } else {
+                    const int obj = __double2loint(rec[j].x), tri = __double2hiint(rec[j].x);
+                    if (id[j] & CAND_TRI) {
+                        int outside; d3 ph; double u, v;
+                        c.visit(prim, obj, 1, tri_t(s.tris[tri], e, &outside, &ph, &u, &v));
+                    } else {
+                        c.visit(prim, obj, 0, plane_t(s.objects[obj], e));
+                    }
+                }
+            }
         }
     }
     c.commit();
@@ -917,7 +956,13 @@ __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, 
 __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const Group &gr, const Work &w,
                                                      uint32_t rid, bool in_range, bool hit, d3 ph, d3 nh) {
     uint32_t n_shadow = 0;
-    for (int g = 0; g < gr.count; g++) {
+    // the counter value every lane's cell had before this wave arrived, still in flight (one returning
+    // atomic per light): all lights' atomics are issued before any result is used
+    uint32_t pending[LIGHT_GROUP], rank_in_wave[LIGHT_GROUP], leader[LIGHT_GROUP];
+#pragma unroll
+    for (int g = 0; g < LIGHT_GROUP; g++) {
+        pending[g] = 0; rank_in_wave[g] = 0; leader[g] = 0;
+        if (g >= gr.count) continue; // uniform
         const Bundle &bd = gr.b[g];
         const size_t at = (size_t)g * w.n + rid;
         uint32_t bin = 0xffffffffu;
@@ -934,9 +979,16 @@ __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const
             w.ray32[at] = nan4();
         }
         if (bd.binned) {
-            const uint32_t rank = wave_bin_rank(w.bin_hist + (size_t)g * (RT_BINS + 2), bin, bin != 0xffffffffu);
-            if (in_range) { w.bin_id[at] = bin; w.bin_rank[at] = rank; }
+            pending[g] = wave_bin_count(w.bin_hist + (size_t)g * (RT_BINS + 2), bin, bin != 0xffffffffu,
+                                        rank_in_wave[g], leader[g]);
+            if (in_range) w.bin_id[at] = bin;
         }
+    }
+#pragma unroll
+    for (int g = 0; g < LIGHT_GROUP; g++) {
+        if (g >= gr.count || !gr.b[g].binned) continue; // uniform
+        const uint32_t base = (uint32_t)__shfl((int)pending[g], (int)leader[g], 64);
+        if (in_range) w.bin_rank[(size_t)g * w.n + rid] = base + rank_in_wave[g];
     }
     return n_shadow;
 }
@@ -1015,7 +1067,10 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
 // Shader::shading's loop over the lights (shader.h:60-94) for the lights of one group: colour before
 // the shadow (shader.h:75-89), CalcShadow on the light's candidates (shader.h:393-433), the running
 // mean (shader.h:93); then either the next group's shadow rays or the pixel store (main.cpp:367-369).
-__global__ __launch_bounds__(256) void k_shade_group(SceneView s, ShaderView sh, Frame f, Work w, Group cur,
+#ifndef SHADE_MIN_WAVES
+#define SHADE_MIN_WAVES 3 // waves per SIMD the shading kernel's register budget allows
+#endif
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView s, ShaderView sh, Frame f, Work w, Group cur,
                                                      Group next, unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_eval = 0, n_over = 0;
@@ -1139,6 +1194,12 @@ inline h3 hnormalize(h3 v) { // vector3D.h:79-88
     return v;
 }
 inline void put3(double *d, h3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+inline double4 index_rec(int32_t obj, int32_t tri) { // (obj, tri) in the first 8 bytes of a primitive record
+    double4 r = make_double4(0, 0, 0, 0);
+    int32_t v[2] = {obj, tri};
+    memcpy(&r.x, v, sizeof v);
+    return r;
+}
 inline uint32_t pack_rgb(const uint8_t *c) { return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16); }
 } // namespace
 
@@ -1196,6 +1257,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     std::vector<DObject> objs(d->n_objects);
     std::vector<DTriangle> tris(d->n_triangles);
     std::vector<int32_t> prim_obj, prim_tri;
+    std::vector<double4> prim_rec;
     double rmax = 0, extent = 0;
     for (int i = 0; i < d->n_objects; i++) {
         const rt355_object &o = d->objects[i];
@@ -1223,10 +1285,16 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         if (o.type == RT355_OBJ_MESH) {
             if (o.tri_begin < 0 || o.tri_count < 0 || (int64_t)o.tri_begin + o.tri_count > d->n_triangles)
                 return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": triangle range out of bounds");
-            for (int k = 0; k < o.tri_count; k++) { prim_obj.push_back(i); prim_tri.push_back(o.tri_begin + k); }
+            for (int k = 0; k < o.tri_count; k++) {
+                prim_obj.push_back(i); prim_tri.push_back(o.tri_begin + k);
+                prim_rec.push_back(index_rec(i, o.tri_begin + k));
+            }
         } else {
             prim_obj.push_back(i); prim_tri.push_back(-1);
+            prim_rec.push_back(o.type == RT355_OBJ_SPHERE ? make_double4(o.p[0], o.p[1], o.p[2], o.radius) : index_rec(i, -1));
         }
+        if (prim_obj.size() > (size_t)CAND_INDEX)
+            return fail(RT355_ERR_UNSUPPORTED, "more than 2^30 - 1 primitives");
     }
     for (int i = 0; i < d->n_triangles; i++) { // Triangle ctor, anyobject.h:456-461
         const rt355_triangle &t = d->triangles[i];
@@ -1257,6 +1325,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     int rc;
     if ((rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
         (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
+        (rc = upload(sc, prim_rec, &sc->view.prim_rec)) ||
         (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels))) {
         rt355_scene_destroy(sc);
         return rc;
