@@ -106,6 +106,13 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t tile_stride, list_stride;
 };
 
+// Kernels that work on the rays of several lights at once take the workspace slot from blockIdx.y
+// (or blockIdx.x for the one-workgroup scans) through this map.
+struct Slots {
+    int32_t count;
+    int32_t slot[LIGHT_GROUP];
+};
+
 // Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
 // counter block (each on its own 128-byte line); the host adds the shards up.
 #define COUNTER_SHARDS 64
@@ -140,10 +147,9 @@ __device__ __forceinline__ uint32_t cand_kind(const SceneView &s, int i) {
 // -thr = -2 "never" (triangles facing the wrong way for the whole bundle, padding).
 // L2[3i..3i+2] = inward unit normals of the three planes through the origin and a triangle
 // edge; d can only hit the triangle if d . n >= -eps for all three.  Zero rows always pass.
-__global__ void k_bundle_origin(SceneView s, d3 O, int is_eye, int n_padded, float4 *__restrict__ L1,
-                                float4 *__restrict__ L2, float *__restrict__ L1s) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_padded) return;
+__device__ __forceinline__ void bundle_origin_row(const SceneView &s, d3 O, int is_eye, int i,
+                                                  float4 *__restrict__ L1, float4 *__restrict__ L2,
+                                                  float *__restrict__ L1s) {
     float4 never = make_float4(0.f, 0.f, 0.f, -2.f), always = make_float4(0.f, 0.f, 0.f, 2.f);
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 l1 = never, a = z4, b = z4, c = z4;
@@ -223,6 +229,7 @@ struct Bundle {
     int kind;     // 0 = not searched (fp64 brute force), 1 = common origin, 2 = common direction
     d3 o;         // kind 1: the origin
     d3 e1, e2;    // kind 2: basis of the projection plane
+    d3 dir;       // kind 2: the common ray direction (unit)
     double rmaxp; // kind 2: upper bound of (bounding radius + per-primitive rounding bound)
     int binned;   // packet search: the rays of this bundle are also counted into direction bins
     float plane_extent; // kind 2: half-width of the binning grid on the projection plane
@@ -233,10 +240,9 @@ struct Group { // lights k0 .. k0 + count - 1 and the bundles of their shadow ra
     Bundle b[LIGHT_GROUP];
 };
 
-__global__ void k_bundle_direction(SceneView s, Bundle bd, d3 w, int n_padded, float4 *__restrict__ L1,
-                                   float4 *__restrict__ L2) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_padded) return;
+__device__ __forceinline__ void bundle_direction_row(const SceneView &s, const Bundle &bd, int i,
+                                                     float4 *__restrict__ L1, float4 *__restrict__ L2) {
+    const d3 w = bd.dir;
     const float inf = __builtin_inff();
     // .w = the circle's radius for the packet search's beam test: NaN "never", +inf "always"
     float4 never = make_float4(0.f, 0.f, -inf, __builtin_nanf("")), always = make_float4(0.f, 0.f, inf, inf);
@@ -291,6 +297,24 @@ __global__ void k_bundle_direction(SceneView s, Bundle bd, d3 w, int n_padded, f
     L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
 }
 
+// table of the camera rays' bundle (slot 0)
+__global__ void k_bundle_eye(SceneView s, d3 O, int n_padded, float4 *__restrict__ L1, float4 *__restrict__ L2,
+                             float *__restrict__ L1s) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_padded) bundle_origin_row(s, O, 1, i, L1, L2, L1s);
+}
+// tables of the shadow-ray bundles of a group of lights, slot = blockIdx.y
+__global__ void k_bundle_group(SceneView s, Group gr, int n_padded, float4 *__restrict__ L1, float4 *__restrict__ L2,
+                               float *__restrict__ L1s) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (i >= n_padded) return;
+    const Bundle &bd = gr.b[g];
+    const size_t off = (size_t)g * n_padded;
+    if (bd.kind == 1) bundle_origin_row(s, bd.o, 0, i, L1 + off, L2 + 3 * off, L1s + off);
+    else if (bd.kind == 2) bundle_direction_row(s, bd, i, L1 + off, L2 + 3 * off);
+}
+
 // fp32 search record of a shadow ray for the given bundle
 __device__ __forceinline__ float4 bundle_ray(const Bundle &bd, d3 ph, d3 nhl) {
     if (bd.kind == 1) return make_float4((float)nhl.x, (float)nhl.y, (float)nhl.z, 0.f);
@@ -324,8 +348,12 @@ __device__ __forceinline__ bool ray_active(const float4 *__restrict__ ray32, uin
     return x == x; // inactive rays hold NaN
 }
 
-__global__ __launch_bounds__(SEARCH_THREADS) void k_count_active(const float4 *__restrict__ ray32,
-                                                                  uint32_t *__restrict__ tile_count) {
+__global__ __launch_bounds__(SEARCH_THREADS) void k_count_active(const float4 *__restrict__ ray32_all,
+                                                                  uint32_t *__restrict__ tile_count_all,
+                                                                  uint32_t n_rays, uint32_t tile_stride, Slots sl) {
+    const size_t g = (size_t)sl.slot[blockIdx.y];
+    const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
+    uint32_t *__restrict__ tile_count = tile_count_all + g * tile_stride;
     __shared__ uint32_t wsum[SEARCH_THREADS / 64];
     const uint32_t t = threadIdx.x, base = blockIdx.x * RAYS_PER_TILE + t;
     uint32_t n = 0;
@@ -339,7 +367,9 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_count_active(const float4 *_
 }
 
 // exclusive scan of n_tiles counts in place (single workgroup); tile_count[n_tiles] = total
-__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *__restrict__ tile_count, int n_tiles) {
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *__restrict__ tile_count_all, int n_tiles,
+                                                     uint32_t tile_stride, Slots sl) {
+    uint32_t *__restrict__ tile_count = tile_count_all + (size_t)sl.slot[blockIdx.x] * tile_stride;
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
     const int per = (n_tiles + 1023) / 1024;
@@ -359,9 +389,15 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *__restrict__ tile
     if (t == 1023) tile_count[n_tiles] = part[1023];
 }
 
-__global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 *__restrict__ ray32,
-                                                                    const uint32_t *__restrict__ tile_count,
-                                                                    uint32_t *__restrict__ active_rid) {
+__global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 *__restrict__ ray32_all,
+                                                                    const uint32_t *__restrict__ tile_count_all,
+                                                                    uint32_t *__restrict__ active_rid_all,
+                                                                    uint32_t n_rays, uint32_t tile_stride,
+                                                                    uint32_t list_stride, Slots sl) {
+    const size_t g = (size_t)sl.slot[blockIdx.y];
+    const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
+    const uint32_t *__restrict__ tile_count = tile_count_all + g * tile_stride;
+    uint32_t *__restrict__ active_rid = active_rid_all + g * list_stride;
     __shared__ uint32_t wsum[RAYS_PER_THREAD][SEARCH_THREADS / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
@@ -454,10 +490,15 @@ __device__ __forceinline__ uint32_t wave_bin_count(uint32_t *__restrict__ hist, 
     return base; // valid in the group's first lane; the lane's rank in its cell is that value + rank
 }
 // position of every active ray in the direction-sorted list: start of its cell + rank in the cell
-__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id,
-                                                     const uint32_t *__restrict__ bin_rank,
-                                                     const uint32_t *__restrict__ offsets,
-                                                     uint32_t *__restrict__ active_rid) {
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id_all,
+                                                     const uint32_t *__restrict__ bin_rank_all,
+                                                     const uint32_t *__restrict__ offsets_all,
+                                                     uint32_t *__restrict__ active_rid_all, uint32_t n_rays,
+                                                     uint32_t list_stride, Slots sl) {
+    const size_t g = (size_t)sl.slot[blockIdx.y];
+    const uint32_t *__restrict__ bin_id = bin_id_all + g * n_rays, *__restrict__ bin_rank = bin_rank_all + g * n_rays;
+    const uint32_t *__restrict__ offsets = offsets_all + g * (RT_BINS + 2);
+    uint32_t *__restrict__ active_rid = active_rid_all + g * list_stride;
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // the ray count is a multiple of the block size
     uint32_t bin = bin_id[rid];
     if (bin != 0xffffffffu) active_rid[offsets[bin] + bin_rank[rid]] = rid;
@@ -469,7 +510,12 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict_
 // mixes rays of different patches: a wave's beam is never wider than one patch, whatever the ray
 // density.  One workgroup; thread c owns patch c.  hist[RT_BINS + 1] receives the padded total.
 #define RT_PATCH 16
-__global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist, uint32_t *__restrict__ active_rid) {
+__global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist_all,
+                                                    uint32_t *__restrict__ active_rid_all, uint32_t list_stride,
+                                                    Slots sl) {
+    const size_t g = (size_t)sl.slot[blockIdx.x];
+    uint32_t *__restrict__ hist = hist_all + g * (RT_BINS + 2);
+    uint32_t *__restrict__ active_rid = active_rid_all + g * list_stride;
     __shared__ uint32_t part[1024];
     const int c = threadIdx.x;
     uint4 v[RT_PATCH / 4];
@@ -550,13 +596,21 @@ __device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, 
 }
 
 template <int KIND>
-__global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restrict__ L1,
-                                                           const float4 *__restrict__ L2, int n_padded,
-                                                           const float4 *__restrict__ ray32, uint32_t n_rays,
-                                                           const uint32_t *__restrict__ active_rid,
-                                                           const uint32_t *__restrict__ n_active,
-                                                           uint32_t *__restrict__ cand,
-                                                           uint32_t *__restrict__ cand_cnt) {
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restrict__ L1_all,
+                                                           const float4 *__restrict__ L2_all, int n_padded,
+                                                           const float4 *__restrict__ ray32_all, uint32_t n_rays,
+                                                           const uint32_t *__restrict__ active_rid_all,
+                                                           const uint32_t *__restrict__ n_active_all,
+                                                           uint32_t *__restrict__ cand_all,
+                                                           uint32_t *__restrict__ cand_cnt_all, Slots sl,
+                                                           uint32_t list_stride, uint32_t n_active_stride) {
+    // the slot of this launch row: its table, rays, list and candidate arrays
+    const size_t g = (size_t)sl.slot[blockIdx.y];
+    const float4 *__restrict__ L1 = L1_all + g * n_padded, *__restrict__ L2 = L2_all + 3 * g * n_padded;
+    const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
+    const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
+    const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
+    uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
     __shared__ float4 lds[2][PRIM_TILE];
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
@@ -660,15 +714,24 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 #define PACKET_ROUND (PACKET_PER_WAVE * PACKET_WAVES) // chunks per round, one barrier per round
 static_assert(PACKET_ROUND <= 64, "one lane per chunk mask of a round");
 template <int KIND>
-__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *__restrict__ L1,
-                                                                  const float *__restrict__ L1s,
-                                                                  const float4 *__restrict__ L2, int n_padded,
-                                                                  const float4 *__restrict__ ray32, uint32_t n_rays,
-                                                                  const uint32_t *__restrict__ active_rid,
-                                                                  const uint32_t *__restrict__ n_active,
-                                                                  uint32_t *__restrict__ cand,
-                                                                  uint32_t *__restrict__ cand_cnt,
-                                                                  unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *__restrict__ L1_all,
+                                                                  const float *__restrict__ L1s_all,
+                                                                  const float4 *__restrict__ L2_all, int n_padded,
+                                                                  const float4 *__restrict__ ray32_all, uint32_t n_rays,
+                                                                  const uint32_t *__restrict__ active_rid_all,
+                                                                  const uint32_t *__restrict__ n_active_all,
+                                                                  uint32_t *__restrict__ cand_all,
+                                                                  uint32_t *__restrict__ cand_cnt_all,
+                                                                  unsigned long long *__restrict__ counters, Slots sl,
+                                                                  uint32_t list_stride, uint32_t n_active_stride) {
+    // the slot of this launch row: its table, rays, list and candidate arrays
+    const size_t g = (size_t)sl.slot[blockIdx.y];
+    const float4 *__restrict__ L1 = L1_all + g * n_padded, *__restrict__ L2 = L2_all + 3 * g * n_padded;
+    const float *__restrict__ L1s = L1s_all + g * n_padded;
+    const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
+    const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
+    const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
+    uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
     // The workgroup's rays (PACKET_WAVES x 256) share ONE beam.  Its waves split the primitive table
     // between them (chunk c goes to wave c % PACKET_WAVES, read straight from L2 with eight loads
     // in flight), so the table is read once per workgroup and each wave does its share of the beam
@@ -1217,7 +1280,7 @@ struct rt355_scene {
     float *L1s = nullptr;
     Work work{};
     uint32_t work_rays = 0;
-    int work_slots = 0;
+    int work_slots = 0, table_slots = 0;
     DLight *d_lights = nullptr; int lights_cap = 0;
     // timing / stats of the outstanding render
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -1387,10 +1450,12 @@ static int slots_for(uint32_t n_rays, int n_lights) {
 }
 
 static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundles, int n_groups) {
-    if (!sc->L1) {
-        HIP_TRY(hipMalloc((void **)&sc->L1, (size_t)sc->n_padded * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **)&sc->L2, (size_t)sc->n_padded * 3 * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **)&sc->L1s, (size_t)sc->n_padded * sizeof(float)));
+    if (slots > sc->table_slots) { // one bundle table per slot
+        if (sc->L1) { (void)hipFree(sc->L1); (void)hipFree(sc->L2); (void)hipFree(sc->L1s); sc->L1 = sc->L2 = nullptr; sc->L1s = nullptr; sc->table_slots = 0; }
+        HIP_TRY(hipMalloc((void **)&sc->L1, (size_t)slots * sc->n_padded * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&sc->L2, (size_t)slots * sc->n_padded * 3 * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&sc->L1s, (size_t)slots * sc->n_padded * sizeof(float)));
+        sc->table_slots = slots;
     }
     while ((int)sc->ev_search.size() < 2 * n_bundles) {
         hipEvent_t e;
@@ -1474,7 +1539,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     const int nl = shader->n_lights;
     const int slots = slots_for(f.n_rays, nl);
     const int n_groups = (nl + slots - 1) / slots;
-    int rc = ensure_work(sc, f.n_rays, slots, 1 + nl, n_groups);
+    int rc = ensure_work(sc, f.n_rays, slots, 1 + 2 * n_groups, n_groups);
     if (rc) return rc;
 
     // lights -> device
@@ -1502,7 +1567,6 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     // origin: the light position, or common direction for a directional light)
     const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
     std::vector<Bundle> bundles(2 + nl);
-    std::vector<d3> ray_dir(2 + nl);
     for (auto &b : bundles) memset(&b, 0, sizeof b);
     if (can_search) {
         bundles[0].kind = 1;
@@ -1521,7 +1585,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
                 b.kind = 2;
                 b.e1.x = e1.x; b.e1.y = e1.y; b.e1.z = e1.z; b.e2.x = e2.x; b.e2.y = e2.y; b.e2.z = e2.z;
                 b.rmaxp = sc->rmax * (1.0 + 1e-6) + 8.0 * 2.384185791015625e-07 * (sc->extent + sc->rmax) + 1e-30;
-                ray_dir[1 + k].x = w.x; ray_dir[1 + k].y = w.y; ray_dir[1 + k].z = w.z;
+                b.dir.x = w.x; b.dir.y = w.y; b.dir.z = w.z;
             }
         }
     }
@@ -1541,44 +1605,56 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     unsigned char *pix = (unsigned char *)d_pixmap;
     int launches = 0;
     const Work &w = sc->work;
-    // search of bundle bi (0 = camera rays, 1 + k = light k) in workspace slot g
-    auto run_search = [&](int bi, int g) -> int {
-        const Bundle &b = bundles[bi];
-        const bool is_eye = (bi == 0);
-        float4 *ray32 = w.ray32 + (size_t)g * w.n;
-        uint32_t *cand = w.cand + (size_t)g * CAND_CAP * w.n, *cand_cnt = w.cand_cnt + (size_t)g * w.n;
-        uint32_t *tile_count = w.tile_count + (size_t)g * w.tile_stride;
-        uint32_t *active_rid = w.active_rid + (size_t)g * w.list_stride;
-        uint32_t *bin_hist = w.bin_hist + (size_t)g * (RT_BINS + 2);
-        if (b.kind == 1)
-            hipLaunchKernelGGL(k_bundle_origin, dim3(setup_blocks), dim3(256), 0, st, sc->view, b.o, is_eye ? 1 : 0, sc->n_padded, sc->L1, sc->L2, sc->L1s);
-        else
-            hipLaunchKernelGGL(k_bundle_direction, dim3(setup_blocks), dim3(256), 0, st, sc->view, b, ray_dir[bi], sc->n_padded, sc->L1, sc->L2);
-        const uint32_t *list = nullptr, *total = nullptr;
-        if (b.binned) { // the producer of the rays counted them into direction bins: order them
-            hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, bin_hist, active_rid);
-            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks), dim3(256), 0, st, w.bin_id + (size_t)g * w.n, w.bin_rank + (size_t)g * w.n, bin_hist, active_rid);
-            list = active_rid; total = bin_hist + RT_BINS + 1;
-        } else if (!is_eye) { // shadow bundles are sparse: compact their active rays first
-            hipLaunchKernelGGL(k_count_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, ray32, tile_count);
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_count, (int)n_tiles);
-            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, ray32, tile_count, active_rid);
-            list = active_rid; total = tile_count + n_tiles;
-        }
+    const unsigned packet_eye_blocks = (unsigned)(((size_t)f.n_rays + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
+    const unsigned packet_list_blocks = (unsigned)(((size_t)w.list_stride + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
+    // one search launch over the given slots (all of bundle kind `kind`); list / total = null for the camera rays
+    auto launch_search = [&](int kind, const Slots &sl, const uint32_t *list, const uint32_t *total,
+                             uint32_t total_stride) -> int {
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
-            const size_t n_slots = is_eye ? (size_t)f.n_rays : (size_t)w.list_stride;
-            const unsigned n_blocks = (unsigned)((n_slots + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
-            if (b.kind == 1)
-                hipLaunchKernelGGL(k_search_packet<1>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt, w.counters);
+            const dim3 grid(list ? packet_list_blocks : packet_eye_blocks, (unsigned)sl.count);
+            if (kind == 1)
+                hipLaunchKernelGGL(k_search_packet<1>, grid, dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
             else
-                hipLaunchKernelGGL(k_search_packet<2>, dim3(n_blocks), dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt, w.counters);
-        } else if (b.kind == 1)
-            hipLaunchKernelGGL(k_search<1>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt);
-        else
-            hipLaunchKernelGGL(k_search<2>, dim3(n_tiles), dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, ray32, f.n_rays, list, total, cand, cand_cnt);
+                hipLaunchKernelGGL(k_search_packet<2>, grid, dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
+        } else {
+            const dim3 grid(n_tiles, (unsigned)sl.count);
+            if (kind == 1)
+                hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
+            else
+                hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
+        }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
         launches++;
+        return RT355_OK;
+    };
+    // tables, ray lists and searches of all the lights of a group: one launch per step, slot = blockIdx.y
+    auto search_group = [&](const Group &gr) -> int {
+        Slots searched{}, of_kind[3]{};
+        for (int g = 0; g < gr.count; g++)
+            if (gr.b[g].kind) {
+                searched.slot[searched.count++] = g;
+                Slots &k = of_kind[gr.b[g].kind];
+                k.slot[k.count++] = g;
+            }
+        if (!searched.count) return RT355_OK;
+        hipLaunchKernelGGL(k_bundle_group, dim3(setup_blocks, (unsigned)gr.count), dim3(256), 0, st, sc->view, gr, sc->n_padded, sc->L1, sc->L2, sc->L1s);
+        const uint32_t *total; uint32_t total_stride;
+        if (opts->mode == RT355_MODE_PACKET) { // the producer of the rays counted them into direction bins: order them
+            hipLaunchKernelGGL(k_scan_bins, dim3((unsigned)searched.count), dim3(1024), 0, st, w.bin_hist, w.active_rid, w.list_stride, searched);
+            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks, (unsigned)searched.count), dim3(256), 0, st, w.bin_id, w.bin_rank, w.bin_hist, w.active_rid, f.n_rays, w.list_stride, searched);
+            total = w.bin_hist + RT_BINS + 1; total_stride = RT_BINS + 2;
+        } else { // shadow bundles are sparse: compact their active rays first
+            hipLaunchKernelGGL(k_count_active, dim3(n_tiles, (unsigned)searched.count), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, searched);
+            hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)searched.count), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, searched);
+            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, (unsigned)searched.count), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, searched);
+            total = w.tile_count + n_tiles; total_stride = w.tile_stride;
+        }
+        for (int kind = 1; kind <= 2; kind++)
+            if (of_kind[kind].count) {
+                int rc2 = launch_search(kind, of_kind[kind], w.active_rid, total, total_stride);
+                if (rc2) return rc2;
+            }
         return RT355_OK;
     };
     // the lights, in groups of `slots`
@@ -1597,8 +1673,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         return RT355_OK;
     };
     if (bundles[0].kind) {
+        Slots eye{};
+        eye.count = 1;
         hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, w.ray32);
-        if ((rc = run_search(0, 0))) return rc;
+        hipLaunchKernelGGL(k_bundle_eye, dim3(setup_blocks), dim3(256), 0, st, sc->view, bundles[0].o, sc->n_padded, sc->L1, sc->L2, sc->L1s);
+        if ((rc = launch_search(1, eye, nullptr, nullptr, 0))) return rc;
     }
     Group cur = group_of(0);
     if ((rc = clear_bins(cur))) return rc;
@@ -1607,8 +1686,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
                        bundles[0].kind ? 0 : 1, cur, pix);
     HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
     for (int j = 0; j < n_groups; j++) {
-        for (int g = 0; g < cur.count; g++)
-            if (cur.b[g].kind && (rc = run_search(1 + cur.k0 + g, g))) return rc;
+        if ((rc = search_group(cur))) return rc;
         Group next = group_of(j + 1);
         if ((rc = clear_bins(next))) return rc;
         HIP_TRY(hipEventRecord(sc->ev_resolve[2 + 2 * j], st));
