@@ -100,9 +100,9 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *cand;       // [CAND_CAP][n]
     uint32_t *tile_count; // [tile_stride] active rays per tile, then exclusive offsets; entry [tiles] = total
     uint32_t *active_rid; // [list_stride] rids of the slot's active rays, tile-major or direction-sorted
-    uint32_t *bin_hist;   // [RT_BINS + 2] packet search: rays per direction bin, then offsets
+    uint32_t *bin_hist;   // [HIST_STRIDE] packet search: rays per (direction bin, counter shard), then offsets
     uint32_t *bin_id;     // [n] packet search: direction bin of each ray, 0xffffffff = inactive
-    uint32_t *bin_rank;   // [n] packet search: rank of the ray inside its bin
+    uint32_t *bin_rank;   // [n] packet search: rank of the ray among those of its counter
     uint32_t tile_stride, list_stride;
 };
 
@@ -431,6 +431,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_scatter_active(const float4 
 // plane, cells numbered in Morton order so that consecutive cells are neighbours.  Order inside a
 // cell is whatever the atomics give; candidates are per ray, so frames do not depend on it.
 #define RT_BINS 16384 /* 128 x 128 cells */
+// Every cell has RT_SHARDS counters; a ray uses the one of its 256-ray block (block % RT_SHARDS).
+// Neighbouring blocks run at the same time and point the same way, so with one counter per cell
+// their atomics would queue up on one address.  Layout: [cell][shard], then the padded total.
+#ifndef RT_SHARDS
+#define RT_SHARDS 4
+#endif
+#define HIST_TOTAL (RT_BINS * RT_SHARDS + 1)
+#define HIST_STRIDE (RT_BINS * RT_SHARDS + 2)
+__device__ __forceinline__ uint32_t hist_index(uint32_t bin, uint32_t rid) {
+    return bin * RT_SHARDS + (rid / 256u) % RT_SHARDS;
+}
 // index of cell (x, y) of a 128x128 grid along the Hilbert curve: consecutive indices are always
 // neighbouring cells, so any run of consecutive rays covers one connected patch of directions
 __device__ __forceinline__ uint32_t hilbert7(uint32_t x, uint32_t y) {
@@ -489,7 +500,7 @@ __device__ __forceinline__ uint32_t wave_bin_count(uint32_t *__restrict__ hist, 
     if (active && lane == leader_lane) base = atomicAdd(&hist[bin], count);
     return base; // valid in the group's first lane; the lane's rank in its cell is that value + rank
 }
-// position of every active ray in the direction-sorted list: start of its cell + rank in the cell
+// position of every active ray in the direction-sorted list: start of its counter's run + rank in it
 __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id_all,
                                                      const uint32_t *__restrict__ bin_rank_all,
                                                      const uint32_t *__restrict__ offsets_all,
@@ -497,51 +508,78 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict_
                                                      uint32_t list_stride, Slots sl) {
     const size_t g = (size_t)sl.slot[blockIdx.y];
     const uint32_t *__restrict__ bin_id = bin_id_all + g * n_rays, *__restrict__ bin_rank = bin_rank_all + g * n_rays;
-    const uint32_t *__restrict__ offsets = offsets_all + g * (RT_BINS + 2);
+    const uint32_t *__restrict__ offsets = offsets_all + g * HIST_STRIDE;
     uint32_t *__restrict__ active_rid = active_rid_all + g * list_stride;
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // the ray count is a multiple of the block size
     uint32_t bin = bin_id[rid];
-    if (bin != 0xffffffffu) active_rid[offsets[bin] + bin_rank[rid]] = rid;
+    if (bin != 0xffffffffu) active_rid[offsets[hist_index(bin, rid)] + bin_rank[rid]] = rid;
 }
 
 // Offsets of the direction bins, with every run of 16 consecutive bins (a 4x4 patch of cells on
 // the Hilbert curve) padded to a multiple of 256 rays (the padding entries of the sorted list are
 // written here), so that no wave of the packet search
 // mixes rays of different patches: a wave's beam is never wider than one patch, whatever the ray
-// density.  One workgroup; thread c owns patch c.  hist[RT_BINS + 1] receives the padded total.
+// density.  One workgroup per slot; thread c owns patch c (all shards of its cells, contiguous).
+// hist[HIST_TOTAL] receives the padded total.
 #define RT_PATCH 16
 __global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist_all,
                                                     uint32_t *__restrict__ active_rid_all, uint32_t list_stride,
                                                     Slots sl) {
     const size_t g = (size_t)sl.slot[blockIdx.x];
-    uint32_t *__restrict__ hist = hist_all + g * (RT_BINS + 2);
+    uint32_t *__restrict__ hist = hist_all + g * HIST_STRIDE;
     uint32_t *__restrict__ active_rid = active_rid_all + g * list_stride;
+    // Patch p's counters are RT_PATCH * RT_SHARDS contiguous words.  Wave v owns patches 64 v .. 64 v + 63 and
+    // reads each with one coalesced load (PER words per lane): first for the patch sums, then, after the
+    // scan of the padded sums over the workgroup, again to turn the counters into offsets.
     __shared__ uint32_t part[1024];
-    const int c = threadIdx.x;
-    uint4 v[RT_PATCH / 4];
-    const uint4 *src = (const uint4 *)(hist + (size_t)c * RT_PATCH);
-    uint32_t sum = 0;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int PER = RT_PATCH * RT_SHARDS / 64; // words of a patch per lane
+    static_assert(RT_PATCH * RT_SHARDS % 64 == 0 && PER >= 1, "a patch must fill whole wave loads");
+#pragma unroll 4
+    for (int i = 0; i < 64; i++) {
+        const uint32_t *src = hist + ((size_t)(wave * 64 + i) * 64 + lane) * PER;
+        uint32_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < RT_PATCH / 4; i++) { v[i] = src[i]; sum += v[i].x + v[i].y + v[i].z + v[i].w; }
-    const uint32_t padded = (sum + (64u * PACKET_RAYS - 1u)) / (64u * PACKET_RAYS) * (64u * PACKET_RAYS);
-    part[c] = padded;
+        for (int k = 0; k < PER; k++) sum += src[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) part[wave * 64 + i] = sum;
+    }
+    __syncthreads();
+    const uint32_t sum_c = part[t];
+    const uint32_t padded = (sum_c + (64u * PACKET_RAYS - 1u)) / (64u * PACKET_RAYS) * (64u * PACKET_RAYS);
+    __syncthreads();
+    part[t] = padded;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t x = (c >= off) ? part[c - off] : 0u;
+        uint32_t x = (t >= off) ? part[t - off] : 0u;
         __syncthreads();
-        part[c] += x;
+        part[t] += x;
         __syncthreads();
     }
-    uint32_t run = part[c] - padded;
-    for (uint32_t i = run + sum; i < run + padded; i++) active_rid[i] = 0xffffffffu; // padding = no ray
-    uint4 *dst = (uint4 *)(hist + (size_t)c * RT_PATCH);
+    const uint32_t start_c = part[t] - padded; // patch t starts here
+    for (uint32_t i = start_c + sum_c; i < start_c + padded; i++) active_rid[i] = 0xffffffffu; // padding = no ray
+    const uint32_t total = part[1023];
+    __syncthreads();
+    part[t] = start_c;
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 64; i++) {
+        uint32_t *dst = hist + ((size_t)(wave * 64 + i) * 64 + lane) * PER;
+        uint32_t v[PER], mine = 0;
 #pragma unroll
-    for (int i = 0; i < RT_PATCH / 4; i++) {
-        uint4 o;
-        o.x = run; run += v[i].x; o.y = run; run += v[i].y; o.z = run; run += v[i].z; o.w = run; run += v[i].w;
-        dst[i] = o;
+        for (int k = 0; k < PER; k++) { v[k] = dst[k]; mine += v[k]; }
+        uint32_t incl = mine; // inclusive scan of the lanes' sums
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t x = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += x;
+        }
+        uint32_t run = part[wave * 64 + i] + incl - mine;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const uint32_t cnt = v[k]; dst[k] = run; run += cnt; }
     }
-    if (c == 1023) hist[RT_BINS + 1] = part[1023];
+    if (t == 1023) hist[HIST_TOTAL] = total;
 }
 
 // ---- the all-pairs candidate search ------------------------------------------------------------------
@@ -1042,7 +1080,8 @@ __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const
             w.ray32[at] = nan4();
         }
         if (bd.binned) {
-            pending[g] = wave_bin_count(w.bin_hist + (size_t)g * (RT_BINS + 2), bin, bin != 0xffffffffu,
+            pending[g] = wave_bin_count(w.bin_hist + (size_t)g * HIST_STRIDE,
+                                        bin != 0xffffffffu ? hist_index(bin, rid) : bin, bin != 0xffffffffu,
                                         rank_in_wave[g], leader[g]);
             if (in_range) w.bin_id[at] = bin;
         }
@@ -1489,7 +1528,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.cand, g * CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, g * (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.bin_hist, g * (RT_BINS + 2) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.bin_hist, g * HIST_STRIDE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_id, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_rank, g * n * sizeof(uint32_t)));
     sc->work_rays = cap_rays;
@@ -1643,7 +1682,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         if (opts->mode == RT355_MODE_PACKET) { // the producer of the rays counted them into direction bins: order them
             hipLaunchKernelGGL(k_scan_bins, dim3((unsigned)searched.count), dim3(1024), 0, st, w.bin_hist, w.active_rid, w.list_stride, searched);
             hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks, (unsigned)searched.count), dim3(256), 0, st, w.bin_id, w.bin_rank, w.bin_hist, w.active_rid, f.n_rays, w.list_stride, searched);
-            total = w.bin_hist + RT_BINS + 1; total_stride = RT_BINS + 2;
+            total = w.bin_hist + HIST_TOTAL; total_stride = HIST_STRIDE;
         } else { // shadow bundles are sparse: compact their active rays first
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles, (unsigned)searched.count), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, searched);
             hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)searched.count), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, searched);
@@ -1669,7 +1708,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     auto clear_bins = [&](const Group &gr) -> int { // the next kernel counts the group's rays into the bins
         bool any = false;
         for (int g = 0; g < gr.count; g++) any = any || gr.b[g].binned;
-        if (any) HIP_TRY(hipMemsetAsync(w.bin_hist, 0, (size_t)gr.count * (RT_BINS + 2) * sizeof(uint32_t), st));
+        if (any) HIP_TRY(hipMemsetAsync(w.bin_hist, 0, (size_t)gr.count * HIST_STRIDE * sizeof(uint32_t), st));
         return RT355_OK;
     };
     if (bundles[0].kind) {
