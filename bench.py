@@ -105,26 +105,33 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads):
                       f"{st['shadow_rays']} shadow rays, {dt:.2f} s)"}
 
 
-def resolve_bytes(stats, n_rays_padded, n_lights, w, h):
-    """Algorithmic HBM bytes of the fp64 resolve kernels of one frame (per-ray records are SoA):
-    every ray slot reads/writes its 4-byte object id once per kernel; a hit writes its record once
-    (ph, nh, npe = 72 B, obj/cm0/cm1/sum/pre = 20 B) and per light reads ph, pre, sum (32 B), writes sum
-    (4 B) and, unless it is the last light, reads nh, npe, cm0, cm1 (56 B) and writes pre, the fp32 shadow
-    ray and its direction bin (28 B); every ray with a search reads its candidate count and ids; the
-    last kernel stores 3 bytes per pixel."""
-    hits, cands = stats["primary_hits"], stats["exact_tests"]
-    rays = stats["primary_rays"] + stats["shadow_rays"]
-    b = n_rays_padded * 4 * (1 + n_lights)
-    b += hits * (92 + 28 * (1 if n_lights else 0))
-    b += hits * n_lights * 36 + hits * max(0, n_lights - 1) * (56 + 28)
-    b += rays * 4 + cands * 4 + w * h * 3
+def primary_bytes(stats, n_rays_padded, n_lights, searched):
+    """Algorithmic HBM bytes of k_resolve_primary for one frame (all per-ray records are SoA): every ray
+    slot reads its candidate count (if the camera rays were searched) and writes its object id; the
+    camera rays' candidates are read once (4 B each; counted as one per hit, the typical case, because
+    the statistics do not split candidates by bundle); a hit writes ph, nh, reh (72 B), the border
+    weight (8 B) and its two colours (8 B); per light, a shadow ray writes its fp32 record (16 B) and,
+    when the rays are direction-sorted, every slot writes a bin id and a rank (8 B)."""
+    hits = stats["primary_hits"]
+    b = n_rays_padded * (4 + (4 if searched else 0)) + hits * (4 if searched else 0) + hits * 88
+    b += stats["shadow_rays"] * 16 + (n_lights * n_rays_padded * 8 if searched else 0)
     return float(b)
+
+
+def shade_bytes(stats, n_rays_padded, n_lights, w, h, searched):
+    """Algorithmic HBM bytes of k_shade_group for one frame: every slot reads its object id; a hit
+    reads its 88-byte record once; every shadow ray reads its candidate count and candidate ids
+    (4 B each); one RGB8 pixel is stored per pixel."""
+    hits = stats["primary_hits"]
+    cands = max(0, stats["exact_tests"] - hits) if searched else 0
+    return float(n_rays_padded * 4 + hits * 88 + (stats["shadow_rays"] * 4 + cands * 4 if searched else 0) + w * h * 3)
 
 
 def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None):
     """K frames back to back; returns per-frame averages of the HIP-event kernel times and the stats."""
     import time as _t
-    acc = {"search_ms": 0.0, "search_launches": 0, "resolve_ms": 0.0, "resolve_launches": 0, "pairs": 0}
+    acc = {"search_ms": 0.0, "search_launches": 0, "resolve_ms": 0.0, "resolve_launches": 0, "pairs": 0,
+           "primary_ms": 0.0, "shade_ms": 0.0, "shade_launches": 0}
     stats = None
     t0 = _t.perf_counter()
     for _ in range(steps):
@@ -136,6 +143,8 @@ def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None):
         acc["search_ms"] += ms; acc["search_launches"] += n
         ms, n = r.resolve_kernel_ms()
         acc["resolve_ms"] += ms; acc["resolve_launches"] += n
+        per = r.resolve_launch_ms()
+        acc["primary_ms"] += per[0]; acc["shade_ms"] += sum(per[1:]); acc["shade_launches"] += len(per) - 1
         acc["pairs"] += stats["pair_tests"]
     acc["wall_s"] = None  # filled by the caller around its own barriers
     acc["loop_s"] = _t.perf_counter() - t0
@@ -237,43 +246,52 @@ def main():
             "config": {"workload": args.workload, "width": w, "height": h, "primitives": scene.n_primitives,
                        "lights": len(shader.lights), "alias": 0, "shard": args.shard, "search": args.mode,
                        "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"]},
-                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"]},
+                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
+                       "packet_survivors": stats["packet_survivors"]},
         }
-        kernels = {"search_ms_per_frame": round(acc["search_ms"] / args.steps, 4),
-                   "resolve_ms_per_frame": round(acc["resolve_ms"] / args.steps, 4),
-                   "frame_ms": round(ms_per_step, 4)}
+        K = args.steps
+        kernels = {"search_ms_per_frame": round(acc["search_ms"] / K, 4),
+                   "resolve_primary_ms_per_frame": round(acc["primary_ms"] / K, 4),
+                   "shade_ms_per_frame": round(acc["shade_ms"] / K, 4),
+                   "resolve_ms_per_frame": round(acc["resolve_ms"] / K, 4), "frame_ms": round(ms_per_step, 4)}
         out["kernel_time"] = kernels
-        if acc["search_launches"] == 0:
-            # fewer than 64 primitives: no search at all, the frame is the fp64 resolve kernels
-            rb = resolve_bytes(stats, n_rays_padded, len(shader.lights), w, h)
-            avg_ms = acc["resolve_ms"] / acc["resolve_launches"]
-            gbs = rb * args.steps / acc["resolve_launches"] / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_resolve_primary + k_light_resolve (fp64 brute force)",
-                               "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
-        elif args.mode == "allpairs":
-            out["roofline"] = valu_roofline(acc, stats, args.steps)
-        elif acc["resolve_ms"] >= acc["search_ms"]:
-            rb = resolve_bytes(stats, n_rays_padded, len(shader.lights), w, h)
-            avg_ms = acc["resolve_ms"] / acc["resolve_launches"]
-            gbs = rb * args.steps / acc["resolve_launches"] / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_light_resolve (+ k_resolve_primary)",
-                               "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
-                               "launches_per_frame": acc["resolve_launches"] // args.steps,
-                               "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": rb}
-        else:
-            # packet search: every workgroup of 1024 rays streams the whole cone table from L2 once
+        searched = acc["search_launches"] > 0
+        nl = len(shader.lights)
+
+        def hbm_roofline(kernel, bytes_frame, ms_total, launches):
+            avg_ms = ms_total / max(1, launches)
+            gbs = bytes_frame * K / max(1, launches) / (avg_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_frame": launches // K,
+                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": bytes_frame}
+
+        rooflines = {
+            "k_resolve_primary": hbm_roofline("k_resolve_primary", primary_bytes(stats, n_rays_padded, nl, searched),
+                                              acc["primary_ms"], K),
+        }
+        if acc["shade_launches"]:
+            rooflines["k_shade_group"] = hbm_roofline("k_shade_group", shade_bytes(stats, n_rays_padded, nl, w, h, searched),
+                                                      acc["shade_ms"], acc["shade_launches"])
+        if searched and args.mode == "allpairs":
+            rooflines["k_search"] = valu_roofline(acc, stats, K)
+        elif searched:
+            # packet search: every workgroup of 1024 rays streams the whole cone table (20 B per primitive)
+            # from L2 once and reads its rays' records (20 B per ray)
             n_prims_padded = (scene.n_primitives + 511) // 512 * 512
             groups = n_rays_padded / 1024 + stats["shadow_rays"] / 1024.0
             tb = groups * n_prims_padded * 20.0 + (stats["primary_rays"] + stats["shadow_rays"]) * 20.0
             avg_ms = acc["search_ms"] / acc["search_launches"]
-            gbs = tb * args.steps / acc["search_launches"] / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "l2", "kernel": "k_search_packet", "achieved": round(gbs, 1),
-                               "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_L2_GBS, 4),
-                               "traffic": None, "launches_per_frame": acc["search_launches"] // args.steps,
-                               "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": tb,
-                               "note": "table bytes are served by L2 (the table fits), not HBM"}
+            gbs = tb * K / acc["search_launches"] / (avg_ms * 1e-3) / 1e9
+            rooflines["k_search_packet"] = {
+                "bound": "l2", "kernel": "k_search_packet", "achieved": round(gbs, 1), "peak": PEAK_L2_GBS,
+                "unit": "GB/s", "frac": round(gbs / PEAK_L2_GBS, 4), "traffic": None,
+                "launches_per_frame": acc["search_launches"] // K, "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_frame": tb, "note": "table bytes are served by L2 (the table fits), not HBM"}
+        times = {"k_resolve_primary": acc["primary_ms"], "k_shade_group": acc["shade_ms"],
+                 "k_search_packet": acc["search_ms"], "k_search": acc["search_ms"]}
+        dominant = max(rooflines, key=lambda k: times[k])
+        out["roofline"] = rooflines[dominant]
+        out["roofline_other_kernels"] = {k: v for k, v in rooflines.items() if k != dominant}
         if world == 1 and args.mode == "packet" and not args.no_allpairs and acc["search_launches"]:
             o2 = B.opts(w, h, mode=B.MODE_ALLPAIRS)
             k2 = max(1, min(args.steps, 3))

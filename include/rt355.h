@@ -170,8 +170,12 @@ int rt355_scene_sync(rt355_scene *scene);
 /* Summed HIP-event duration (ms) of the candidate-search kernel launches of the last synced
  * render, and their count.  Used by the benchmark's roofline figure. */
 int rt355_scene_search_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *launches);
-/* Same for the fp64 resolve kernels (k_resolve_primary + one k_light_resolve per light). */
+/* Same for the fp64 kernels: the primary resolve (closest hit, hit record, first shadow rays), then
+ * one shading launch per group of lights. */
 int rt355_scene_resolve_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *launches);
+/* HIP-event duration (ms) of the index-th of those launches (0 = primary resolve, 1.. = shading
+ * of light group index - 1). */
+int rt355_scene_resolve_launch_ms(rt355_scene *scene, int32_t index, double *ms);
 
 /* Debug probe: objs[obj]->CalcIntersect(View(pe,npe)) for n host rays (n x 6 doubles: pe, npe)
  * evaluated by the device's fp64 formulas; out = n x 9 doubles (t, ph[3], nh[3], uv[2]; t = -1
@@ -180,7 +184,8 @@ int rt355_scene_resolve_kernel_ms(rt355_scene *scene, double *ms_sum, int32_t *l
 int rt355_probe_intersect(rt355_scene *scene, int obj, const double *rays, int n, double *out);
 
 /* HIP-event duration (ms) of the index-th candidate-search launch of the last synced render
- * (0 = camera rays, then one per searched light in light order). */
+ * (0 = camera rays; then, per group of lights, one launch for the lights with a position and one
+ * for the directional lights, each covering all such lights of the group). */
 int rt355_scene_search_launch_ms(rt355_scene *scene, int32_t index, double *ms);
 
 const char *rt355_last_error(void);

@@ -38,6 +38,7 @@ def lib():
         L.rt355_scene_sync.argtypes = [C.c_void_p]
         L.rt355_scene_search_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.rt355_scene_resolve_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.rt355_scene_resolve_launch_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
         L.rt355_scene_search_launch_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
         L.rt355_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
@@ -100,6 +101,16 @@ class Renderer:
         ms, n = C.c_double(), C.c_int32()
         _check(lib().rt355_scene_resolve_kernel_ms(self.handle, C.byref(ms), C.byref(n)), "resolve_kernel_ms")
         return ms.value, n.value
+
+    def resolve_launch_ms(self):
+        """Per-launch durations (ms) of the last synced render's fp64 kernels: primary resolve, then shading groups."""
+        _, n = self.resolve_kernel_ms()
+        out = []
+        for i in range(n):
+            ms = C.c_double()
+            _check(lib().rt355_scene_resolve_launch_ms(self.handle, i, C.byref(ms)), "resolve_launch_ms")
+            out.append(ms.value)
+        return out
 
     def search_launch_ms(self):
         """Per-launch durations (ms) of the last synced render's search kernels."""

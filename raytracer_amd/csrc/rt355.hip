@@ -1329,7 +1329,7 @@ struct rt355_scene {
     double resolve_ms = 0;
     int search_launches = 0;
     double search_ms = 0;
-    std::vector<double> launch_ms;
+    std::vector<double> launch_ms, resolve_launch_ms;
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
     uint64_t pending_primary = 0, pending_pairs_static = 0;
@@ -1766,10 +1766,12 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         sc->launch_ms[i] = m;
     }
     sc->resolve_ms = 0;
+    sc->resolve_launch_ms.assign(sc->resolve_launches, 0.0);
     for (int i = 0; i < sc->resolve_launches; i++) {
         float m = 0;
         HIP_TRY(hipEventElapsedTime(&m, sc->ev_resolve[2 * i], sc->ev_resolve[2 * i + 1]));
         sc->resolve_ms += m;
+        sc->resolve_launch_ms[i] = m;
     }
     if (sc->pending_stats) {
         rt355_stats *s = sc->pending_stats;
@@ -1808,6 +1810,12 @@ extern "C" int rt355_scene_resolve_kernel_ms(rt355_scene *sc, double *ms_sum, in
     if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
     *ms_sum = sc->resolve_ms;
     *launches = sc->resolve_launches;
+    return RT355_OK;
+}
+
+extern "C" int rt355_scene_resolve_launch_ms(rt355_scene *sc, int32_t index, double *ms) {
+    if (!sc || !ms || index < 0 || index >= (int32_t)sc->resolve_launch_ms.size()) return fail(RT355_ERR_ARG, "bad launch index");
+    *ms = sc->resolve_launch_ms[index];
     return RT355_OK;
 }
 

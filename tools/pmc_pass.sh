@@ -7,4 +7,4 @@ export TMPDIR=/tmp
 timeout -s KILL 120 rocprofv3 --pmc "$@" -d gpurun_out/$tag -- python3 bench.py --steps 3 --warmup 1 --workload $wl --no-allpairs --no-cpu-baseline > gpurun_out/$tag.log 2>&1 || { tail -n 5 gpurun_out/$tag.log; exit 1; }
 db=$(find gpurun_out/$tag -name '*.db' | head -n 1)
 python3 tools/prof_summary.py "$db" > gpurun_out/$tag.txt 2>&1
-grep -E "k_light_resolve|k_resolve_primary|k_search_packet" gpurun_out/$tag.txt
+grep -E "k_shade_group|k_resolve_primary|k_search_packet|k_bin_scatter" gpurun_out/$tag.txt
