@@ -124,10 +124,6 @@ __device__ __forceinline__ void wave_count(unsigned long long *counters, int whi
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + which], (unsigned long long)v);
 }
 
-#ifdef RT355_DEBUG_TIMES
-// debug build only: per-workgroup time stamps of the packet search (100 MHz wall clock)
-__device__ unsigned long long *g_dbg_times = nullptr;
-#endif
 
 __device__ __forceinline__ float4 nan4() {
     float q = __builtin_nanf("");
@@ -135,11 +131,15 @@ __device__ __forceinline__ float4 nan4() {
 }
 
 // ---- bundle tables ---------------------------------------------------------------------------------
-// kind bits the search adds to a candidate's primitive index
-__device__ __forceinline__ uint32_t cand_kind(const SceneView &s, int i) {
-    if (i >= s.n_prims) return 0u;
-    if (s.prim_tri[i] >= 0) return CAND_TRI;
-    return (s.objects[s.prim_obj[i]].type == RT_OBJ_SPHERE) ? CAND_SPHERE : 0u;
+// Table position i holds primitive s.order[i]: the tables are laid out along a space-filling curve
+// through the primitives' centres, so that the 64 primitives of a chunk, and the 64 chunks of a
+// superchunk, are neighbours in space and their common bound is tight.
+__device__ __forceinline__ int table_prim(const SceneView &s, int i) { return (i < s.n_prims) ? s.order[i] : -1; }
+// what the search stores for a candidate: the primitive index plus the kind of exact test it needs
+__device__ __forceinline__ uint32_t cand_id(const SceneView &s, int prim) {
+    if (prim < 0) return 0u;
+    if (s.prim_tri[prim] >= 0) return (uint32_t)prim | CAND_TRI;
+    return (uint32_t)prim | ((s.objects[s.prim_obj[prim]].type == RT_OBJ_SPHERE) ? CAND_SPHERE : 0u);
 }
 // L1[i] = (ox, oy, oz, -thr): unit axis and negated cosine threshold of a cone, seen from the
 // bundle origin, that contains primitive i.  A ray with unit direction d can only hit i if
@@ -147,16 +147,15 @@ __device__ __forceinline__ uint32_t cand_kind(const SceneView &s, int i) {
 // -thr = -2 "never" (triangles facing the wrong way for the whole bundle, padding).
 // L2[3i..3i+2] = inward unit normals of the three planes through the origin and a triangle
 // edge; d can only hit the triangle if d . n >= -eps for all three.  Zero rows always pass.
-__device__ __forceinline__ void bundle_origin_row(const SceneView &s, d3 O, int is_eye, int i,
-                                                  float4 *__restrict__ L1, float4 *__restrict__ L2,
-                                                  float *__restrict__ L1s) {
+struct TableRow { float4 l1, a, b, c; float sin_t; };
+__device__ __forceinline__ TableRow bundle_origin_row(const SceneView &s, d3 O, int is_eye, int i) {
     float4 never = make_float4(0.f, 0.f, 0.f, -2.f), always = make_float4(0.f, 0.f, 0.f, 2.f);
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 l1 = never, a = z4, b = z4, c = z4;
     // L1s[i] = sine of the cone's (inflated) half angle, used by the packet search's beam test:
     // 0 for "always", -inf for "never" (which turns cos(theta + beta) into +inf or NaN: no survivor)
     float sin_t = -__builtin_inff();
-    if (i < s.n_prims) {
+    if (i >= 0) { // i = the primitive, -1 = padding
         int obj = s.prim_obj[i], tri = s.prim_tri[i];
         d3 ctr; double rad; bool sphere_like = false;
         if (tri < 0) {
@@ -208,10 +207,10 @@ __device__ __forceinline__ void bundle_origin_row(const SceneView &s, d3 O, int 
             }
         }
     }
-    a.w = __uint_as_float(cand_kind(s, i));
-    L1[i] = l1;
-    L1s[i] = sin_t;
-    L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
+    a.w = __uint_as_float(cand_id(s, i));
+    TableRow row;
+    row.l1 = l1; row.a = a; row.b = b; row.c = c; row.sin_t = sin_t;
+    return row;
 }
 
 // Bundle of parallel rays (the shadow rays of a directional light, shader.h:76-77): every ray
@@ -240,15 +239,14 @@ struct Group { // lights k0 .. k0 + count - 1 and the bundles of their shadow ra
     Bundle b[LIGHT_GROUP];
 };
 
-__device__ __forceinline__ void bundle_direction_row(const SceneView &s, const Bundle &bd, int i,
-                                                     float4 *__restrict__ L1, float4 *__restrict__ L2) {
+__device__ __forceinline__ TableRow bundle_direction_row(const SceneView &s, const Bundle &bd, int i) {
     const d3 w = bd.dir;
     const float inf = __builtin_inff();
     // .w = the circle's radius for the packet search's beam test: NaN "never", +inf "always"
     float4 never = make_float4(0.f, 0.f, -inf, __builtin_nanf("")), always = make_float4(0.f, 0.f, inf, inf);
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 l1 = never, a = z4, b = z4, c = z4;
-    if (i < s.n_prims) {
+    if (i >= 0) { // i = the primitive, -1 = padding
         int obj = s.prim_obj[i], tri = s.prim_tri[i];
         d3 ctr; double rad = 0; bool round_like = false;
         if (tri < 0) {
@@ -292,27 +290,126 @@ __device__ __forceinline__ void bundle_direction_row(const SceneView &s, const B
             l1 = make_float4((float)uc, (float)vc, (float)(R * R * (1.0 + 1e-6)), (float)(R * (1.0 + 1e-6)));
         }
     }
-    a.w = __uint_as_float(cand_kind(s, i));
-    L1[i] = l1;
-    L2[3 * (size_t)i] = a; L2[3 * (size_t)i + 1] = b; L2[3 * (size_t)i + 2] = c;
+    a.w = __uint_as_float(cand_id(s, i));
+    TableRow row;
+    row.l1 = l1; row.a = a; row.b = b; row.c = c; row.sin_t = 0.f;
+    return row;
 }
 
-// table of the camera rays' bundle (slot 0)
-__global__ void k_bundle_eye(SceneView s, d3 O, int n_padded, float4 *__restrict__ L1, float4 *__restrict__ L2,
-                             float *__restrict__ L1s) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_padded) bundle_origin_row(s, O, 1, i, L1, L2, L1s);
+// ---- bounds of bounds ----------------------------------------------------------------------------------
+// One record bounding the 64 records held by the lanes of a wave, in the records' own format, so
+// that the beam test of the packet search applies to every level alike.
+//   kind 1: cone (unit axis, -cos, sin of the half angle) containing every member cone: axis = mean
+//           of the member axes, half angle = max over members of (angle to the axis + own half angle).
+//           Angles come from chord lengths (accurate for small angles) in double, plus 1e-5 rad.
+//   kind 2: circle (centre, R^2, R) containing every member circle.
+// "never" members are skipped, one "always" member makes the bound "always".
+struct Bound { float4 p; float s; };
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ Bound bound_of_wave(int kind, float4 p, float st) {
+    Bound out;
+    const float inf = __builtin_inff();
+    if (kind == 1) {
+        const bool always = p.w >= 1.5f, never = p.w <= -1.5f, valid = !always && !never;
+        const int n_valid = __popcll(__ballot(valid));
+        out.p = make_float4(0.f, 0.f, 0.f, -2.f); out.s = -inf; // never
+        if (__ballot(always)) { out.p.w = 2.f; out.s = 0.f; return out; }
+        if (!n_valid) return out;
+        double ax = wave_sum_d(valid ? (double)p.x : 0.0), ay = wave_sum_d(valid ? (double)p.y : 0.0),
+               az = wave_sum_d(valid ? (double)p.z : 0.0);
+        const double len = sqrt(ax * ax + ay * ay + az * az);
+        double total = 0.0;
+        if (len > 1e-3 * n_valid) {
+            ax /= len; ay /= len; az /= len;
+            if (valid) {
+                const double dx = ax - p.x, dy = ay - p.y, dz = az - p.z;
+                const double chord = sqrt(dx * dx + dy * dy + dz * dz);
+                const double own = acos(fmin(1.0, fmax(-1.0, -(double)p.w)));
+                total = 2.0 * asin(fmin(1.0, 0.5 * chord)) + own;
+            }
+            total = wave_max_d(total) + 1e-5;
+        } else {
+            total = 4.0; // the axes cancel out: no useful cone
+        }
+        if (total >= 1.5) { out.p.w = 2.f; out.s = 0.f; return out; }
+        out.p = make_float4((float)ax, (float)ay, (float)az, (float)(-(cos(total) - 1e-6)));
+        out.s = (float)(sin(total) * (1.0 + 1e-6) + 1e-6);
+        return out;
+    }
+    const bool always = p.w == inf, never = !(p.w == p.w), valid = !always && !never;
+    const int n_valid = __popcll(__ballot(valid));
+    out.p = make_float4(0.f, 0.f, -inf, __builtin_nanf("")); out.s = 0.f; // never
+    if (__ballot(always)) { out.p.z = inf; out.p.w = inf; return out; }
+    if (!n_valid) return out;
+    const double cx = wave_sum_d(valid ? (double)p.x : 0.0) / n_valid, cy = wave_sum_d(valid ? (double)p.y : 0.0) / n_valid;
+    double reach = 0.0;
+    if (valid) {
+        const double dx = p.x - cx, dy = p.y - cy;
+        reach = sqrt(dx * dx + dy * dy) + (double)p.w;
+    }
+    const double R = wave_max_d(reach) * (1.0 + 1e-6) + 4.0 * RT_EPS22 * (fabs(cx) + fabs(cy)) + 1e-30;
+    if (!(R < 1e30)) { out.p.z = inf; out.p.w = inf; return out; }
+    out.p = make_float4((float)cx, (float)cy, (float)(R * R * (1.0 + 1e-6)), (float)(R * (1.0 + 1e-6)));
+    return out;
+}
+
+// The tables of one bundle (one workspace slot).  n_table = 4096 * superchunks >= the padded
+// primitive count; chunk c = rows 64 c .. 64 c + 63, superchunk s = chunks 64 s .. 64 s + 63.
+struct Tables {
+    float4 *L1;  float *L1s;  // [n_table] primitive bounds (L1s: sine of the cone's half angle, kind 1)
+    float4 *L2;               // [3 n_table] pyramid / edge rows; row 0 .w = candidate id
+    float4 *C1;  float *C1s;  // [n_table / 64] chunk bounds
+    float4 *S1;  float *S1s;  // [top_stride] superchunk bounds, padded to whole wave loads with "never"
+    int32_t n_table, top_stride;
+};
+__device__ __forceinline__ Tables slot_tables(const Tables &t, size_t g) {
+    Tables o = t;
+    o.L1 += g * t.n_table; o.L1s += g * t.n_table; o.L2 += 3 * g * t.n_table;
+    o.C1 += g * (t.n_table / 64); o.C1s += g * (t.n_table / 64);
+    o.S1 += g * t.top_stride; o.S1s += g * t.top_stride;
+    return o;
+}
+
+// rows and chunk bounds of one bundle: thread = table position, wave = chunk
+__device__ __forceinline__ void write_rows(const SceneView &s, const Bundle &bd, int is_eye, const Tables &t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // < n_table (the grid covers it exactly)
+    const int prim = table_prim(s, i);
+    const TableRow row = (bd.kind == 1) ? bundle_origin_row(s, bd.o, is_eye, prim) : bundle_direction_row(s, bd, prim);
+    t.L1[i] = row.l1;
+    t.L1s[i] = row.sin_t;
+    t.L2[3 * (size_t)i] = row.a; t.L2[3 * (size_t)i + 1] = row.b; t.L2[3 * (size_t)i + 2] = row.c;
+    const Bound bnd = bound_of_wave(bd.kind, row.l1, row.sin_t);
+    if ((threadIdx.x & 63) == 0) { t.C1[i / 64] = bnd.p; t.C1s[i / 64] = bnd.s; }
+}
+// table of the camera rays' bundle (slot 0)
+__global__ __launch_bounds__(256) void k_bundle_eye(SceneView s, Bundle bd, Tables t) { write_rows(s, bd, 1, t); }
 // tables of the shadow-ray bundles of a group of lights, slot = blockIdx.y
-__global__ void k_bundle_group(SceneView s, Group gr, int n_padded, float4 *__restrict__ L1, float4 *__restrict__ L2,
-                               float *__restrict__ L1s) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_bundle_group(SceneView s, Group gr, Tables t) {
+    const Bundle &bd = gr.b[blockIdx.y];
+    if (bd.kind) write_rows(s, bd, 0, slot_tables(t, blockIdx.y));
+}
+// superchunk bounds from the chunk bounds: thread = chunk, wave = superchunk; slot = blockIdx.y.
+// The grid covers top_stride * 64 chunks; those past the table are "never".
+__global__ __launch_bounds__(256) void k_bundle_up(Group gr, Tables t_all) {
     const int g = blockIdx.y;
-    if (i >= n_padded) return;
-    const Bundle &bd = gr.b[g];
-    const size_t off = (size_t)g * n_padded;
-    if (bd.kind == 1) bundle_origin_row(s, bd.o, 0, i, L1 + off, L2 + 3 * off, L1s + off);
-    else if (bd.kind == 2) bundle_direction_row(s, bd, i, L1 + off, L2 + 3 * off);
+    const int kind = gr.b[g].kind;
+    if (!kind) return;
+    const Tables t = slot_tables(t_all, g);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 p = (kind == 1) ? make_float4(0.f, 0.f, 0.f, -2.f) : make_float4(0.f, 0.f, -__builtin_inff(), __builtin_nanf(""));
+    float st = (kind == 1) ? -__builtin_inff() : 0.f;
+    if (c < t.n_table / 64) { p = t.C1[c]; st = t.C1s[c]; }
+    const Bound bnd = bound_of_wave(kind, p, st);
+    if ((threadIdx.x & 63) == 0) { t.S1[c / 64] = bnd.p; t.S1s[c / 64] = bnd.s; }
 }
 
 // fp32 search record of a shadow ray for the given bundle
@@ -605,8 +702,8 @@ __device__ __forceinline__ float pair_margin(float x, float y, float z, const fl
 }
 
 template <int KIND>
-__device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, const float4 &c, uint32_t prim, float x,
-                                            float y, float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
+__device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, const float4 &c, float x, float y,
+                                            float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
                                             uint32_t &cnt) {
     float ea, eb, ec, floor_;
     if (KIND == 1) { // direction inside the pyramid over the triangle
@@ -621,21 +718,20 @@ __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, co
         floor_ = -lin;
     }
     if (fminf(ea, fminf(eb, ec)) >= floor_) {
-        if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = prim | __float_as_uint(a.w);
+        if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = __float_as_uint(a.w); // row 0 carries the candidate id
         cnt++;
     }
 }
 template <int KIND>
-__device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t prim, float x, float y,
+__device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t row, float x, float y,
                                                  float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
                                                  uint32_t &cnt) {
-    const float4 a = L2[3 * (size_t)prim], b = L2[3 * (size_t)prim + 1], c = L2[3 * (size_t)prim + 2];
-    append_rows<KIND>(a, b, c, prim, x, y, z, lin, rid, n_rays, cand, cnt);
+    const float4 a = L2[3 * (size_t)row], b = L2[3 * (size_t)row + 1], c = L2[3 * (size_t)row + 2];
+    append_rows<KIND>(a, b, c, x, y, z, lin, rid, n_rays, cand, cnt);
 }
 
 template <int KIND>
-__global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restrict__ L1_all,
-                                                           const float4 *__restrict__ L2_all, int n_padded,
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_padded,
                                                            const float4 *__restrict__ ray32_all, uint32_t n_rays,
                                                            const uint32_t *__restrict__ active_rid_all,
                                                            const uint32_t *__restrict__ n_active_all,
@@ -644,7 +740,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
                                                            uint32_t list_stride, uint32_t n_active_stride) {
     // the slot of this launch row: its table, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
-    const float4 *__restrict__ L1 = L1_all + g * n_padded, *__restrict__ L2 = L2_all + 3 * g * n_padded;
+    const Tables tb = slot_tables(t_all, g);
+    const float4 *__restrict__ L1 = tb.L1, *__restrict__ L2 = tb.L2;
     const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
@@ -717,16 +814,18 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(const float4 *__restr
         if (base + r * SEARCH_THREADS < total) cand_cnt[rid[r]] = cnt[r];
 }
 
-// ---- packet search: one beam test per (wave, primitive), pair tests only for the survivors -----------
-// The 1024 rays of a workgroup are neighbours (on screen for camera rays, in direction for the
-// sorted shadow rays), so they fit in a narrow beam: a cone around their mean direction
-// (common-origin bundles) or a disc around their mean projected origin (common-direction bundles).
-// A primitive whose bounding cone / circle misses the beam cannot be a candidate of any of those
-// rays.  Lanes take 64 primitives at a time (one coalesced 1 KiB read of the table, served from
-// L2), test beam against bound, and __ballot the survivors; only those (a handful per workgroup)
-// get the per-ray test of k_search.  Every primitive is still looked at by every workgroup --
-// there is no hierarchy over the primitives -- but the work per (ray, primitive) pair drops from
-// 3.6 VALU instructions to ~0.01.
+// ---- packet search: beams against a three-level table ---------------------------------------------------
+// The 256 rays of a wave are neighbours (on screen for camera rays, in direction for the sorted
+// shadow rays), so they fit in a narrow beam: a cone around their mean direction (common-origin
+// bundles) or a disc around their mean projected origin (common-direction bundles).  A primitive
+// whose bounding cone / circle misses the beam cannot be a candidate of any of those rays, and
+// neither can any primitive of a chunk or superchunk whose bound misses it.  The wave walks the
+// table top down, 64 records per step (one coalesced 1 KiB read, served from L2): superchunk
+// bounds, the chunk bounds of the surviving superchunks, the primitive records of the surviving
+// chunks; each step is one beam test per lane and a __ballot.  Only the surviving primitives (a
+// handful per wave) get the per-ray test of k_search, with operands broadcast from registers.
+// Waves do not cooperate, so there is no barrier and no LDS; candidates come out in table order,
+// which the exact resolve does not depend on.
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -746,15 +845,8 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-#ifndef PACKET_PER_WAVE
-#define PACKET_PER_WAVE 4 // chunks of 64 primitives a wave tests per round (all loads in flight together)
-#endif
-#define PACKET_ROUND (PACKET_PER_WAVE * PACKET_WAVES) // chunks per round, one barrier per round
-static_assert(PACKET_ROUND <= 64, "one lane per chunk mask of a round");
 template <int KIND>
-__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *__restrict__ L1_all,
-                                                                  const float *__restrict__ L1s_all,
-                                                                  const float4 *__restrict__ L2_all, int n_padded,
+__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                                                                   const float4 *__restrict__ ray32_all, uint32_t n_rays,
                                                                   const uint32_t *__restrict__ active_rid_all,
                                                                   const uint32_t *__restrict__ n_active_all,
@@ -762,28 +854,16 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *
                                                                   uint32_t *__restrict__ cand_cnt_all,
                                                                   unsigned long long *__restrict__ counters, Slots sl,
                                                                   uint32_t list_stride, uint32_t n_active_stride) {
-    // the slot of this launch row: its table, rays, list and candidate arrays
+    // the slot of this launch row: its tables, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
-    const float4 *__restrict__ L1 = L1_all + g * n_padded, *__restrict__ L2 = L2_all + 3 * g * n_padded;
-    const float *__restrict__ L1s = L1s_all + g * n_padded;
+    const Tables tb = slot_tables(t_all, g);
     const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
-    // The workgroup's rays (PACKET_WAVES x 256) share ONE beam.  Its waves split the primitive table
-    // between them (chunk c goes to wave c % PACKET_WAVES, read straight from L2 with eight loads
-    // in flight), so the table is read once per workgroup and each wave does its share of the beam
-    // tests.  Survivor masks are exchanged through LDS, one barrier per round; then every wave
-    // walks the masks in primitive order, filters the surviving chunks with its OWN narrower beam,
-    // and runs the per-ray test for what is left.
-    __shared__ unsigned long long masks[2][PACKET_ROUND];
-    __shared__ float red[PACKET_WAVES][8];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t total = active_rid ? *n_active : n_rays;
     if (blockIdx.x * PACKET_BLOCK_RAYS >= total) return;
-#ifdef RT355_DEBUG_TIMES
-    const unsigned long long dbg_t0 = wall_clock64();
-#endif
     float rx[PACKET_RAYS], ry[PACKET_RAYS], rz[PACKET_RAYS], rw[PACKET_RAYS];
     uint32_t cnt[PACKET_RAYS], rid[PACKET_RAYS];
     bool live[PACKET_RAYS];
@@ -808,151 +888,101 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *
             if (KIND == 1) sz += q.z; else msq_max = fmaxf(msq_max, q.z);
         }
     }
-    // ---- beams.  Each wave has its own (used to filter the workgroup's survivors before any
-    // per-ray work); the workgroup's is built from the per-wave sums through LDS.
+    // ---- the wave's beam
     sx = wave_sum_f(sx); sy = wave_sum_f(sy); sz = wave_sum_f(sz); nact = wave_sum_f(nact);
     msq_max = wave_max_f(msq_max);
-    const bool wave_live = nact > 0.f;
-    if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; red[wave][3] = nact; red[wave][4] = msq_max; }
-    __syncthreads();
-    float bx = 0.f, by = 0.f, bz = 0.f, bn = 0.f, bmsq = 0.f;
-#pragma unroll
-    for (int v = 0; v < PACKET_WAVES; v++) {
-        bx += red[v][0]; by += red[v][1]; bz += red[v][2]; bn += red[v][3]; bmsq = fmaxf(bmsq, red[v][4]);
-    }
-    if (!(bn > 0.f)) { // nothing to search for in this workgroup (uniform)
+    if (!(nact > 0.f)) { // nothing to search for in this wave (uniform)
 #pragma unroll
         for (int r = 0; r < PACKET_RAYS; r++) if (live[r]) cand_cnt[rid[r]] = 0;
         return;
     }
-    // axis / centre of the wave beam (w*) and of the workgroup beam (g*), and their spreads
-    float wx, wy, wz = 0.f, gx, gy, gz = 0.f, w_spread, g_spread;
-    bool w_all = false, g_all = false; // degenerate beam: every primitive survives
+    float wx, wy, wz = 0.f, w_cos = -1.f, w_sin = 0.f, w_rho = 0.f;
+    bool w_all = false; // degenerate beam: everything survives
     if (KIND == 1) {
-        const float wl2 = sx * sx + sy * sy + sz * sz, gl2 = bx * bx + by * by + bz * bz;
-        const float wi = 1.0f / sqrtf(fmaxf(wl2, 1e-30f)), gi = 1.0f / sqrtf(fmaxf(gl2, 1e-30f));
+        const float wl2 = sx * sx + sy * sy + sz * sz;
+        const float wi = 1.0f / sqrtf(fmaxf(wl2, 1e-30f));
         wx = sx * wi; wy = sy * wi; wz = sz * wi;
-        gx = bx * gi; gy = by * gi; gz = bz * gi;
-        float wlo = 1.f, glo = 1.f;
+        float wlo = 1.f;
 #pragma unroll
         for (int r = 0; r < PACKET_RAYS; r++)
-            if (rx[r] == rx[r]) {
-                wlo = fminf(wlo, __builtin_fmaf(rz[r], wz, __builtin_fmaf(ry[r], wy, rx[r] * wx)));
-                glo = fminf(glo, __builtin_fmaf(rz[r], gz, __builtin_fmaf(ry[r], gy, rx[r] * gx)));
-            }
-        w_spread = wave_min_f(wlo); g_spread = wave_min_f(glo);
-        w_all = !(wl2 > 1e-12f); g_all = !(gl2 > 1e-12f);
-    } else {
-        const float wi = 1.0f / fmaxf(nact, 1.f), gi = 1.0f / bn;
-        wx = sx * wi; wy = sy * wi; gx = bx * gi; gy = by * gi;
-        float wfar = 0.f, gfar = 0.f;
-#pragma unroll
-        for (int r = 0; r < PACKET_RAYS; r++)
-            if (rx[r] == rx[r]) {
-                float du = rx[r] - wx, dv = ry[r] - wy;
-                wfar = fmaxf(wfar, __builtin_fmaf(du, du, dv * dv));
-                du = rx[r] - gx; dv = ry[r] - gy;
-                gfar = fmaxf(gfar, __builtin_fmaf(du, du, dv * dv));
-            }
-        w_spread = wave_max_f(wfar); g_spread = wave_max_f(gfar);
-    }
-    if (lane == 0) red[wave][5] = g_spread;
-    __syncthreads();
-    float g_cos = -1.f, g_sin = 0.f, g_rho = 0.f, w_cos = -1.f, w_sin = 0.f, w_rho = 0.f;
-    if (KIND == 1) {
-        g_spread = red[0][5];
-#pragma unroll
-        for (int v = 1; v < PACKET_WAVES; v++) g_spread = fminf(g_spread, red[v][5]);
-        g_cos = fmaxf(g_spread - 2e-6f, -1.f); g_sin = sqrtf(fmaxf(0.f, 1.f - g_cos * g_cos));
+            if (rx[r] == rx[r]) wlo = fminf(wlo, __builtin_fmaf(rz[r], wz, __builtin_fmaf(ry[r], wy, rx[r] * wx)));
+        const float w_spread = wave_min_f(wlo);
+        w_all = !(wl2 > 1e-12f);
         w_cos = fmaxf(w_spread - 2e-6f, -1.f); w_sin = sqrtf(fmaxf(0.f, 1.f - w_cos * w_cos));
     } else {
-        g_spread = red[0][5];
+        const float wi = 1.0f / fmaxf(nact, 1.f);
+        wx = sx * wi; wy = sy * wi;
+        float wfar = 0.f;
 #pragma unroll
-        for (int v = 1; v < PACKET_WAVES; v++) g_spread = fmaxf(g_spread, red[v][5]);
-        g_rho = sqrtf(g_spread); g_rho = g_rho * (1.f + 1e-5f) + 4e-6f * (fabsf(gx) + fabsf(gy) + g_rho);
-        w_rho = sqrtf(w_spread); w_rho = w_rho * (1.f + 1e-5f) + 4e-6f * (fabsf(wx) + fabsf(wy) + w_rho);
-        g_all = !(g_rho == g_rho) || !(g_rho < 3.0e38f);
+        for (int r = 0; r < PACKET_RAYS; r++)
+            if (rx[r] == rx[r]) {
+                const float du = rx[r] - wx, dv = ry[r] - wy;
+                wfar = fmaxf(wfar, __builtin_fmaf(du, du, dv * dv));
+            }
+        w_rho = sqrtf(wave_max_f(wfar));
+        w_rho = w_rho * (1.f + 1e-5f) + 4e-6f * (fabsf(wx) + fabsf(wy) + w_rho);
         w_all = !(w_rho == w_rho) || !(w_rho < 3.0e38f);
     }
-    if (g_all) { g_cos = -1.f; g_sin = 0.f; g_rho = __builtin_inff(); }
     if (w_all) { w_cos = -1.f; w_sin = 0.f; w_rho = __builtin_inff(); }
 
-    // does the bound of a primitive record meet a beam?
-    auto meets = [&](const float4 &p, float st, float ax_, float ay_, float az_, float cosb, float sinb,
-                     float rho, float msq) -> bool {
+    // does the bound held in a record (of any level) meet the beam?
+    auto meets = [&](const float4 &p, float st) -> bool {
         if (KIND == 1) {
             // cone (axis o, half angle theta) meets beam (axis a, half angle beta) iff
             // a.o >= cos(theta + beta), or theta + beta >= pi.  p.w = -cos(theta), st = sin(theta).
-            const float ca = __builtin_fmaf(az_, p.z, __builtin_fmaf(ay_, p.y, ax_ * p.x));
-            const float rhs = __builtin_fmaf(p.w, -cosb, __builtin_fmaf(st, -sinb, -4e-6f));
-            return (ca >= rhs) || (p.w >= cosb); // second term: theta + beta >= pi, and the "always" records
+            const float ca = __builtin_fmaf(wz, p.z, __builtin_fmaf(wy, p.y, wx * p.x));
+            const float rhs = __builtin_fmaf(p.w, -w_cos, __builtin_fmaf(st, -w_sin, -4e-6f));
+            return (ca >= rhs) || (p.w >= w_cos); // second term: theta + beta >= pi, and the "always" records
         }
         // circle (centre c, radius R) meets disc (centre a, radius rho) iff |c - a| <= R + rho
-        const float du = p.x - ax_, dv = p.y - ay_;
+        const float du = p.x - wx, dv = p.y - wy;
         const float d2 = __builtin_fmaf(du, du, dv * dv);
-        const float R = p.w + rho;
-        return d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq);
+        const float R = p.w + w_rho;
+        return d2 <= __builtin_fmaf(R, R * (1.f + 1e-5f), msq_max);
     };
 
     uint32_t n_surv = 0;
-    const int n_chunks = n_padded / 64;
-    const int n_rounds = (n_chunks + PACKET_ROUND - 1) / PACKET_ROUND;
-    float4 pc[PACKET_PER_WAVE];
-    float ps[PACKET_PER_WAVE];
-    auto fetch_round = [&](int round) {
-#pragma unroll
-        for (int k = 0; k < PACKET_PER_WAVE; k++) {
-            const int chunk = round * PACKET_ROUND + (int)wave + PACKET_WAVES * k;
-            const size_t at = (size_t)min(chunk, n_chunks - 1) * 64 + lane;
-            pc[k] = L1[at];
-            ps[k] = (KIND == 1) ? L1s[at] : 0.f;
-        }
-    };
-    fetch_round(0);
-    for (int round = 0; round < n_rounds; round++) {
-        const int buf = round & 1;
-        // ---- this wave's share of the workgroup-beam tests
-#pragma unroll
-        for (int k = 0; k < PACKET_PER_WAVE; k++) {
-            const int chunk = round * PACKET_ROUND + (int)wave + PACKET_WAVES * k;
-            const bool surv = meets(pc[k], ps[k], gx, gy, gz, g_cos, g_sin, g_rho, bmsq);
-            const unsigned long long m = (chunk < n_chunks) ? __ballot(surv) : 0ull;
-            if (lane == 0) masks[buf][wave + PACKET_WAVES * k] = m;
-        }
-        if (round + 1 < n_rounds) fetch_round(round + 1); // in flight across the barrier and the survivor walk
-        __syncthreads();
-        // ---- surviving chunks of the round, in primitive order.  A surviving chunk is reloaded
-        // whole (cone records and pyramid rows, five coalesced reads, the next chunk's already in
-        // flight), filtered with this wave's own beam, and only then come the per-ray tests, which
-        // take their operands from registers (readlane), never from memory.
-        if (wave_live) {
-            const unsigned long long mine = (lane < PACKET_ROUND) ? masks[buf][lane] : 0ull;
-            unsigned long long which = __ballot(mine != 0ull);
-            float4 np, na, nb, nc; float nst = 0.f;
+    const int n_super = tb.n_table / 4096;
+    for (int top = 0; top * 64 < n_super; top++) {
+        // ---- 64 superchunk bounds
+        const float4 e2 = tb.S1[top * 64 + lane];
+        const float e2s = (KIND == 1) ? tb.S1s[top * 64 + lane] : 0.f;
+        unsigned long long m_super = __ballot(meets(e2, e2s));
+        float4 nq; float nqs = 0.f; // chunk bounds of the next surviving superchunk, in flight
+        auto fetch_super = [&](int sc) {
+            nq = tb.C1[(size_t)sc * 64 + lane];
+            nqs = (KIND == 1) ? tb.C1s[(size_t)sc * 64 + lane] : 0.f;
+        };
+        int s_next = m_super ? top * 64 + __builtin_ctzll(m_super) : 0;
+        if (m_super) fetch_super(s_next);
+        while (m_super) {
+            const int sc = s_next;
+            m_super &= m_super - 1ull;
+            const float4 e1 = nq; const float e1s = nqs;
+            if (m_super) { s_next = top * 64 + __builtin_ctzll(m_super); fetch_super(s_next); }
+            // ---- the 64 chunk bounds of superchunk sc
+            unsigned long long m_chunk = __ballot(meets(e1, e1s));
+            float4 np, na, nb, nc; float nst = 0.f; // rows of the next surviving chunk, in flight
             auto fetch_chunk = [&](int c) {
-                const size_t at = (size_t)(round * PACKET_ROUND + c) * 64 + lane;
-                np = L1[at]; nst = (KIND == 1) ? L1s[at] : 0.f;
-                na = L2[3 * at]; nb = L2[3 * at + 1]; nc = L2[3 * at + 2];
+                const size_t at = ((size_t)sc * 64 + c) * 64 + lane;
+                np = tb.L1[at]; nst = (KIND == 1) ? tb.L1s[at] : 0.f;
+                na = tb.L2[3 * at]; nb = tb.L2[3 * at + 1]; nc = tb.L2[3 * at + 2];
             };
-            int c_next = which ? __builtin_ctzll(which) : 0;
-            if (which) fetch_chunk(c_next);
-            while (which) {
-                const int c = c_next;
-                which &= which - 1ull;
+            int c_next = m_chunk ? __builtin_ctzll(m_chunk) : 0;
+            if (m_chunk) fetch_chunk(c_next);
+            while (m_chunk) {
+                m_chunk &= m_chunk - 1ull;
                 const float4 p = np, ra = na, rb = nb, rc = nc;
                 const float st = nst;
-                if (which) { c_next = __builtin_ctzll(which); fetch_chunk(c_next); }
-                const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, c);
-                const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), c);
-                const bool surv = meets(p, st, wx, wy, wz, w_cos, w_sin, w_rho, msq_max);
-                unsigned long long mask = __ballot(surv) & (((unsigned long long)m_hi << 32) | m_lo);
+                if (m_chunk) { c_next = __builtin_ctzll(m_chunk); fetch_chunk(c_next); }
+                // ---- the 64 primitives of the chunk
+                unsigned long long mask = __ballot(meets(p, st));
                 n_surv += (uint32_t)__popcll(mask);
                 while (mask) {
                     const int i = __builtin_ctzll(mask);
                     mask &= mask - 1ull;
                     float4 q;
                     q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
-                    const uint32_t prim = (uint32_t)((round * PACKET_ROUND + c) * 64 + i);
                     bool hit[PACKET_RAYS];
                     bool any_hit = false;
 #pragma unroll
@@ -963,12 +993,12 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *
                     if (any_hit) { // some ray is inside the cone / circle: pyramid / edge-function rows
                         float4 ea, eb, ec;
                         ea.x = lane_bcast(ra.x, i); ea.y = lane_bcast(ra.y, i); ea.z = lane_bcast(ra.z, i);
-                        ea.w = lane_bcast(ra.w, i); // the kind bits of the candidate id
+                        ea.w = lane_bcast(ra.w, i); // the candidate id
                         eb.x = lane_bcast(rb.x, i); eb.y = lane_bcast(rb.y, i); eb.z = lane_bcast(rb.z, i); eb.w = 0.f;
                         ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
 #pragma unroll
                         for (int r = 0; r < PACKET_RAYS; r++)
-                            if (hit[r]) append_rows<KIND>(ea, eb, ec, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                            if (hit[r]) append_rows<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
                     }
                 }
             }
@@ -977,12 +1007,6 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *
 #pragma unroll
     for (int r = 0; r < PACKET_RAYS; r++)
         if (live[r]) cand_cnt[rid[r]] = cnt[r];
-#ifdef RT355_DEBUG_TIMES
-    if (g_dbg_times && lane == 0) {
-        unsigned long long *rec = g_dbg_times + ((size_t)blockIdx.x * PACKET_WAVES + wave) * 4;
-        rec[0] = dbg_t0; rec[1] = wall_clock64(); rec[2] = n_surv; rec[3] = (unsigned long long)nact;
-    }
-#endif
     if (lane == 0 && n_surv) {
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
 #ifdef RT355_DEBUG_SURVIVORS
@@ -995,6 +1019,15 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(const float4 *
 }
 
 // ---- fp64 closest hit over a ray's candidates (or over everything) -----------------------------------
+// The candidates of a ray come in table order, not list order, so the list-order rules of the
+// reference are restated without order: the closest-hit loop (main.cpp:65-79) keeps the FIRST object
+// with the smallest t >= 0, i.e. the smallest (t, index) pair; a Mesh reports the first triangle with
+// its smallest t >= 0, but only if that t is > 0 (the same loop inside Mesh::CalcIntersect), so a
+// triangle hit at exactly t = 0 removes the whole mesh.  Hence: smallest (t, primitive) over sphere and
+// plane hits with t >= 0 and triangle hits with t > 0, leaving out the triangles of a mesh that has a
+// hit at t = 0.  Such a mesh is only known once all candidates were seen, so if the winner belongs to it
+// the candidates are walked once more without it; two such meshes send the ray to the ordered walk over
+// everything (as does a candidate list that overflowed).
 __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                             uint32_t n_rays, const uint32_t *__restrict__ cand,
                                             const uint32_t *__restrict__ cand_cnt, Closest &c,
@@ -1005,43 +1038,61 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
         n = cand_cnt[rid];
         if (n > CAND_CAP) { brute = true; overflowed += 1; }
     }
+    if (!brute) {
+        const uint32_t *cp = cand + rid;
+        int zero_obj = -1, exclude = -1;
+        bool two_zero = false;
+        for (int pass = 0; pass < 2; pass++) {
+            double bt = RT_FLT_MAX;
+            int bprim = -1, bobj = -1;
+            // CAND_BATCH candidates at a time: first their ids, then their 32-byte records (independent
+            // loads, all in flight together), then the tests
+            for (uint32_t k0 = 0; k0 < n; k0 += CAND_BATCH) {
+                uint32_t id[CAND_BATCH];
+                double4 rec[CAND_BATCH];
+#pragma unroll
+                for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
+#pragma unroll
+                for (int j = 0; j < CAND_BATCH; j++) rec[j] = s.prim_rec[id[j] & CAND_INDEX];
+#pragma unroll
+                for (int j = 0; j < CAND_BATCH; j++) {
+                    if (k0 + j >= n) break;
+                    const int prim = (int)(id[j] & CAND_INDEX);
+                    double t; int obj = -1;
+                    if (id[j] & CAND_SPHERE) {
+                        t = sphere_t_rec(rec[j], e);
+                    } else if (id[j] & CAND_TRI) {
+                        obj = __double2loint(rec[j].x);
+                        if (obj == exclude) continue;
+                        int outside; d3 ph; double u, v;
+                        t = tri_t(s.tris[__double2hiint(rec[j].x)], e, &outside, &ph, &u, &v);
+                        if (t == 0) { // also -0.0
+                            if (zero_obj >= 0 && zero_obj != obj) two_zero = true;
+                            zero_obj = obj;
+                            continue;
+                        }
+                    } else {
+                        t = plane_t(s.objects[__double2loint(rec[j].x)], e);
+                    }
+                    if (t >= 0 && (t < bt || (t == bt && prim < bprim))) { bt = t; bprim = prim; bobj = obj; }
+                }
+            }
+            c.t_best = bt; c.prim_best = bprim;
+            if (pass == 0 && zero_obj >= 0 && bobj == zero_obj && !two_zero) exclude = zero_obj; // once more without it
+            else break;
+        }
+        if (two_zero) brute = true;
+    }
     if (brute) {
+        c.init();
         for (int prim = 0; prim < s.n_prims; prim++) {
             int is_mesh, obj;
             double t = prim_t(s, prim, e, &is_mesh, &obj);
             c.visit(prim, obj, is_mesh, t);
         }
+        c.commit();
         n = (uint32_t)s.n_prims;
-    } else {
-        // CAND_BATCH candidates at a time: first their ids, then their 32-byte records (independent
-        // loads, all in flight together), then the tests in list order
-        const uint32_t *cp = cand + rid;
-        for (uint32_t k0 = 0; k0 < n; k0 += CAND_BATCH) {
-            uint32_t id[CAND_BATCH];
-            double4 rec[CAND_BATCH];
-#pragma unroll
-            for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
-#pragma unroll
-            for (int j = 0; j < CAND_BATCH; j++) rec[j] = s.prim_rec[id[j] & CAND_INDEX];
-#pragma unroll
-            for (int j = 0; j < CAND_BATCH; j++) {
-                if (k0 + j >= n) break;
-                const int prim = (int)(id[j] & CAND_INDEX);
-                if (id[j] & CAND_SPHERE) {
-                    c.visit(prim, -2 - prim, 0, sphere_t_rec(rec[j], e));
-                } else {
-                    const int obj = __double2loint(rec[j].x), tri = __double2hiint(rec[j].x);
-                    if (id[j] & CAND_TRI) {
-                        int outside; d3 ph; double u, v;
-                        c.visit(prim, obj, 1, tri_t(s.tris[tri], e, &outside, &ph, &u, &v));
-                    } else {
-                        c.visit(prim, obj, 0, plane_t(s.objects[obj], e));
-                    }
-                }
-            }
-        }
     }
-    c.commit();
     evaluated += n;
 }
 
@@ -1315,8 +1366,8 @@ struct rt355_scene {
     // owned device allocations of the scene
     std::vector<void *> owned;
     // per-render bundle tables and per-ray workspace (grown on demand)
-    float4 *L1 = nullptr, *L2 = nullptr;
-    float *L1s = nullptr;
+    Tables tables{};   // one set per workspace slot
+    int n_table = 0;   // table rows per slot: whole superchunks (multiples of 4096) >= n_padded
     Work work{};
     uint32_t work_rays = 0;
     int work_slots = 0, table_slots = 0;
@@ -1422,12 +1473,55 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         tex[i].offset = pool.size(); tex[i].sx = t.sx; tex[i].sy = t.sy; tex[i].width = t.width; tex[i].height = t.height;
         pool.insert(pool.end(), t.rgb, t.rgb + (size_t)t.width * t.height * 3);
     }
+    // Search-table order: primitives sorted along a Morton curve through their centres (planes, which no
+    // cone or circle bounds, first), so that table neighbours are neighbours in space.
+    std::vector<int32_t> order(prim_obj.size());
+    {
+        const size_t np = prim_obj.size();
+        std::vector<h3> ctr(np);
+        std::vector<char> finite(np, 0);
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = 0; i < np; i++) {
+            if (prim_tri[i] >= 0) { ctr[i] = H3(tris[prim_tri[i]].p_center); finite[i] = 1; }
+            else if (objs[prim_obj[i]].type == RT355_OBJ_SPHERE) { ctr[i] = H3(objs[prim_obj[i]].p); finite[i] = 1; }
+            const double v[3] = {ctr[i].x, ctr[i].y, ctr[i].z};
+            if (finite[i] && std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2])) {
+                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], v[a]); hi[a] = std::max(hi[a], v[a]); }
+            } else {
+                finite[i] = 0;
+            }
+        }
+        auto spread = [](uint64_t v) { // 21 bits -> every third bit
+            v &= 0x1fffffull;
+            v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+            v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+            v = (v | v << 2) & 0x1249249249249249ull;
+            return v;
+        };
+        std::vector<std::pair<uint64_t, int32_t>> keyed(np);
+        for (size_t i = 0; i < np; i++) {
+            uint64_t key = 0;
+            if (finite[i]) {
+                const double v[3] = {ctr[i].x, ctr[i].y, ctr[i].z};
+                uint64_t q[3];
+                for (int a = 0; a < 3; a++) {
+                    const double span = hi[a] - lo[a];
+                    const double u = span > 0 ? (v[a] - lo[a]) / span : 0.0;
+                    q[a] = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
+                }
+                key = 1 + (spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2);
+            }
+            keyed[i] = {key, (int32_t)i};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t i = 0; i < np; i++) order[i] = keyed[i].second;
+    }
     rt355_scene *sc = new rt355_scene();
     HIP_TRY(hipGetDevice(&sc->device));
     int rc;
     if ((rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
         (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
-        (rc = upload(sc, prim_rec, &sc->view.prim_rec)) ||
+        (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || (rc = upload(sc, order, &sc->view.order)) ||
         (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels))) {
         rt355_scene_destroy(sc);
         return rc;
@@ -1436,6 +1530,9 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->view.n_prims = (int)prim_obj.size();
     sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
     if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
+    sc->n_table = (sc->n_padded + 4095) / 4096 * 4096;
+    sc->tables.n_table = sc->n_table;
+    sc->tables.top_stride = (sc->n_table / 4096 + 63) / 64 * 64;
     sc->has_tris = d->n_triangles > 0;
     sc->rmax = rmax; sc->extent = extent;
     HIP_TRY(hipEventCreate(&sc->ev_begin));
@@ -1446,6 +1543,16 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->work.counters = (unsigned long long *)ctr;
     *out = sc;
     return RT355_OK;
+}
+
+static void free_tables(rt355_scene *sc) {
+    Tables &t = sc->tables;
+    void *ps[] = {t.L1, t.L1s, t.L2, t.C1, t.C1s, t.S1, t.S1s};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    const int n_table = t.n_table, top_stride = t.top_stride;
+    t = Tables{};
+    t.n_table = n_table; t.top_stride = top_stride;
+    sc->table_slots = 0;
 }
 
 static void free_work(rt355_scene *sc) {
@@ -1467,9 +1574,7 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     else (void)hipDeviceSynchronize();
     free_work(sc);
     for (void *p : sc->owned) (void)hipFree(p);
-    if (sc->L1) (void)hipFree(sc->L1);
-    if (sc->L2) (void)hipFree(sc->L2);
-    if (sc->L1s) (void)hipFree(sc->L1s);
+    free_tables(sc);
     if (sc->d_lights) (void)hipFree(sc->d_lights);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
@@ -1489,11 +1594,17 @@ static int slots_for(uint32_t n_rays, int n_lights) {
 }
 
 static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundles, int n_groups) {
-    if (slots > sc->table_slots) { // one bundle table per slot
-        if (sc->L1) { (void)hipFree(sc->L1); (void)hipFree(sc->L2); (void)hipFree(sc->L1s); sc->L1 = sc->L2 = nullptr; sc->L1s = nullptr; sc->table_slots = 0; }
-        HIP_TRY(hipMalloc((void **)&sc->L1, (size_t)slots * sc->n_padded * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **)&sc->L2, (size_t)slots * sc->n_padded * 3 * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **)&sc->L1s, (size_t)slots * sc->n_padded * sizeof(float)));
+    if (slots > sc->table_slots) { // one set of bundle tables per slot
+        free_tables(sc);
+        Tables &t = sc->tables;
+        const size_t rows = (size_t)slots * t.n_table, chunks = rows / 64, tops = (size_t)slots * t.top_stride;
+        HIP_TRY(hipMalloc((void **)&t.L1, rows * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&t.L1s, rows * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&t.L2, rows * 3 * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&t.C1, chunks * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&t.C1s, chunks * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&t.S1, tops * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&t.S1s, tops * sizeof(float)));
         sc->table_slots = slots;
     }
     while ((int)sc->ev_search.size() < 2 * n_bundles) {
@@ -1639,7 +1750,8 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     HIP_TRY(hipEventRecord(sc->ev_begin, st));
     HIP_TRY(hipMemsetAsync(sc->work.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
     const unsigned per_ray_blocks = (f.n_rays + 255) / 256;
-    const unsigned setup_blocks = (sc->n_padded + 255) / 256;
+    const unsigned table_blocks = (unsigned)(sc->n_table / 256);            // one thread per table row
+    const unsigned top_blocks = (unsigned)(sc->tables.top_stride * 64 / 256); // one thread per chunk, padding included
     const unsigned n_tiles = (unsigned)(f.tiles_x * f.tiles_y);
     unsigned char *pix = (unsigned char *)d_pixmap;
     int launches = 0;
@@ -1653,15 +1765,15 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         if (opts->mode == RT355_MODE_PACKET) {
             const dim3 grid(list ? packet_list_blocks : packet_eye_blocks, (unsigned)sl.count);
             if (kind == 1)
-                hipLaunchKernelGGL(k_search_packet<1>, grid, dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search_packet<1>, grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
             else
-                hipLaunchKernelGGL(k_search_packet<2>, grid, dim3(PACKET_THREADS), 0, st, sc->L1, sc->L1s, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search_packet<2>, grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
         } else {
             const dim3 grid(n_tiles, (unsigned)sl.count);
             if (kind == 1)
-                hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
             else
-                hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->L1, sc->L2, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
         launches++;
@@ -1677,7 +1789,8 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
                 k.slot[k.count++] = g;
             }
         if (!searched.count) return RT355_OK;
-        hipLaunchKernelGGL(k_bundle_group, dim3(setup_blocks, (unsigned)gr.count), dim3(256), 0, st, sc->view, gr, sc->n_padded, sc->L1, sc->L2, sc->L1s);
+        hipLaunchKernelGGL(k_bundle_group, dim3(table_blocks, (unsigned)gr.count), dim3(256), 0, st, sc->view, gr, sc->tables);
+        hipLaunchKernelGGL(k_bundle_up, dim3(top_blocks, (unsigned)gr.count), dim3(256), 0, st, gr, sc->tables);
         const uint32_t *total; uint32_t total_stride;
         if (opts->mode == RT355_MODE_PACKET) { // the producer of the rays counted them into direction bins: order them
             hipLaunchKernelGGL(k_scan_bins, dim3((unsigned)searched.count), dim3(1024), 0, st, w.bin_hist, w.active_rid, w.list_stride, searched);
@@ -1715,7 +1828,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         Slots eye{};
         eye.count = 1;
         hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, w.ray32);
-        hipLaunchKernelGGL(k_bundle_eye, dim3(setup_blocks), dim3(256), 0, st, sc->view, bundles[0].o, sc->n_padded, sc->L1, sc->L2, sc->L1s);
+        Group eye_group;
+        memset(&eye_group, 0, sizeof eye_group);
+        eye_group.count = 1; eye_group.b[0] = bundles[0];
+        hipLaunchKernelGGL(k_bundle_eye, dim3(table_blocks), dim3(256), 0, st, sc->view, bundles[0], sc->tables);
+        hipLaunchKernelGGL(k_bundle_up, dim3(top_blocks, 1), dim3(256), 0, st, eye_group, sc->tables);
         if ((rc = launch_search(1, eye, nullptr, nullptr, 0))) return rc;
     }
     Group cur = group_of(0);
@@ -1797,14 +1914,6 @@ extern "C" int rt355_scene_search_kernel_ms(rt355_scene *sc, double *ms_sum, int
     return RT355_OK;
 }
 
-#ifdef RT355_DEBUG_TIMES
-// debug build only: device buffer of 16 * workgroups unsigned long longs, or null to switch off
-extern "C" int rt355_debug_set_times_buffer(void *dptr) {
-    unsigned long long *p = (unsigned long long *)dptr;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_times), &p, sizeof p));
-    return RT355_OK;
-}
-#endif
 
 extern "C" int rt355_scene_resolve_kernel_ms(rt355_scene *sc, double *ms_sum, int32_t *launches) {
     if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");

@@ -170,13 +170,11 @@ __device__ __forceinline__ double tri_t(const DTriangle &t, const Ray &e, int *o
 struct Closest {
     double t_best; int prim_best;
     double t_obj; int prim_obj; int cur_obj; int cur_is_mesh;
-    // cur_obj is a key of the object whose primitives are being visited: its index, or any other value
-    // unique to it except -1 (a sphere visited through its primitive record uses -2 - primitive)
     __device__ __forceinline__ void init() {
         t_best = RT_FLT_MAX; prim_best = -1; t_obj = RT_FLT_MAX; prim_obj = -1; cur_obj = -1; cur_is_mesh = 0;
     }
     __device__ __forceinline__ void commit() {
-        if (cur_obj == -1) return;
+        if (cur_obj < 0) return;
         double tt = t_obj;
         if (cur_is_mesh) { if (!(t_obj > 0 && t_obj != RT_FLT_MAX)) tt = -1; }
         else if (t_obj == RT_FLT_MAX) tt = -1;
@@ -194,6 +192,7 @@ struct SceneView { // device pointers of an uploaded scene
     const DTriangle *tris;
     const int32_t *prim_obj;   // primitive -> object index
     const int32_t *prim_tri;   // primitive -> triangle index, or -1 for a plane / sphere
+    const int32_t *order;      // search-table position -> primitive (primitives along a space-filling curve)
     const double4 *prim_rec;   // primitive -> 32-byte record for the candidate tests: a sphere's centre and
                                // radius; for a triangle or plane the first 8 bytes hold (object, triangle)
     const DTexture *textures;
