@@ -32,7 +32,6 @@ if ROOT not in sys.path:
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (= the f32-input MFMA peak), datasheet
 PEAK_HBM_GBS = 8000.0     # HBM3E peak, datasheet (about 6300 GB/s is achievable)
-PEAK_L2_GBS = 34500.0     # aggregate L2 bandwidth of the 8 XCDs (measured figure of the microarchitecture guide)
 # flops per ray/primitive test of the REFERENCE formulas (common sub-expressions shared):
 ALGO_FLOPS = {"sphere": 18.0, "plane": 14.0, "tri_front": 50.0, "tri_culled": 13.0}
 # flops the search kernel EXECUTES per pair: 3 FMA (6) + its share of the max-fold (8 max3 per
@@ -275,18 +274,10 @@ def main():
         if searched and args.mode == "allpairs":
             rooflines["k_search"] = valu_roofline(acc, stats, K)
         elif searched:
-            # packet search: every workgroup of 1024 rays streams the whole cone table (20 B per primitive)
-            # from L2 once and reads its rays' records (20 B per ray)
-            n_prims_padded = (scene.n_primitives + 511) // 512 * 512
-            groups = n_rays_padded / 1024 + stats["shadow_rays"] / 1024.0
-            tb = groups * n_prims_padded * 20.0 + (stats["primary_rays"] + stats["shadow_rays"]) * 20.0
-            avg_ms = acc["search_ms"] / acc["search_launches"]
-            gbs = tb * K / acc["search_launches"] / (avg_ms * 1e-3) / 1e9
-            rooflines["k_search_packet"] = {
-                "bound": "l2", "kernel": "k_search_packet", "achieved": round(gbs, 1), "peak": PEAK_L2_GBS,
-                "unit": "GB/s", "frac": round(gbs / PEAK_L2_GBS, 4), "traffic": None,
-                "launches_per_frame": acc["search_launches"] // K, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_frame": tb, "note": "table bytes are served by L2 (the table fits), not HBM"}
+            # packet search: the tables stay in L2; per ray it reads the list entry (4 B, shadow rays only) and
+            # the fp32 record (16 B) and writes the candidate count (4 B) and 4 B per candidate
+            sb = stats["primary_rays"] * 20.0 + stats["shadow_rays"] * 24.0 + stats["exact_tests"] * 4.0
+            rooflines["k_search_packet"] = hbm_roofline("k_search_packet", sb, acc["search_ms"], acc["search_launches"])
         times = {"k_resolve_primary": acc["primary_ms"], "k_shade_group": acc["shade_ms"],
                  "k_search_packet": acc["search_ms"], "k_search": acc["search_ms"]}
         dominant = max(rooflines, key=lambda k: times[k])

@@ -722,6 +722,11 @@ __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, co
         cnt++;
     }
 }
+// a primitive without rows (sphere, plane): inside the cone / circle is all there is to test
+__device__ __forceinline__ void append_id(uint32_t id, uint32_t rid, uint32_t n_rays, uint32_t *cand, uint32_t &cnt) {
+    if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = id;
+    cnt++;
+}
 template <int KIND>
 __device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t row, float x, float y,
                                                  float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
@@ -990,15 +995,22 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                         hit[r] = pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f);
                         any_hit |= hit[r];
                     }
-                    if (any_hit) { // some ray is inside the cone / circle: pyramid / edge-function rows
+                    if (!any_hit) continue;
+                    // some ray is inside the cone / circle; triangles also have pyramid / edge-function rows
+                    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(ra.w), i); // the candidate id
+                    if (id & CAND_TRI) {
                         float4 ea, eb, ec;
                         ea.x = lane_bcast(ra.x, i); ea.y = lane_bcast(ra.y, i); ea.z = lane_bcast(ra.z, i);
-                        ea.w = lane_bcast(ra.w, i); // the candidate id
+                        ea.w = __uint_as_float(id);
                         eb.x = lane_bcast(rb.x, i); eb.y = lane_bcast(rb.y, i); eb.z = lane_bcast(rb.z, i); eb.w = 0.f;
                         ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
 #pragma unroll
                         for (int r = 0; r < PACKET_RAYS; r++)
                             if (hit[r]) append_rows<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < PACKET_RAYS; r++)
+                            if (hit[r]) append_id(id, rid[r], n_rays, cand, cnt[r]);
                     }
                 }
             }
