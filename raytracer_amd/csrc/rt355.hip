@@ -110,7 +110,8 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
 // (or blockIdx.x for the one-workgroup scans) through this map.
 struct Slots {
     int32_t count;
-    int32_t slot[LIGHT_GROUP];
+    int32_t slot[LIGHT_GROUP];  // workspace slot (rays, lists, candidates)
+    int32_t table[LIGHT_GROUP]; // table slot of the bundle
 };
 
 // Statistics are summed per wave and added by one lane to one of COUNTER_SHARDS copies of the
@@ -131,10 +132,6 @@ __device__ __forceinline__ float4 nan4() {
 }
 
 // ---- bundle tables ---------------------------------------------------------------------------------
-// Table position i holds primitive s.order[i]: the tables are laid out along a space-filling curve
-// through the primitives' centres, so that the 64 primitives of a chunk, and the 64 chunks of a
-// superchunk, are neighbours in space and their common bound is tight.
-__device__ __forceinline__ int table_prim(const SceneView &s, int i) { return (i < s.n_prims) ? s.order[i] : -1; }
 // what the search stores for a candidate: the primitive index plus the kind of exact test it needs
 __device__ __forceinline__ uint32_t cand_id(const SceneView &s, int prim) {
     if (prim < 0) return 0u;
@@ -148,14 +145,14 @@ __device__ __forceinline__ uint32_t cand_id(const SceneView &s, int prim) {
 // L2[3i..3i+2] = inward unit normals of the three planes through the origin and a triangle
 // edge; d can only hit the triangle if d . n >= -eps for all three.  Zero rows always pass.
 struct TableRow { float4 l1, a, b, c; float sin_t; };
-__device__ __forceinline__ TableRow bundle_origin_row(const SceneView &s, d3 O, int is_eye, int i) {
+__device__ __forceinline__ TableRow bundle_origin_row(const SceneView &s, d3 O, int is_eye, int i) { // i = the primitive
     float4 never = make_float4(0.f, 0.f, 0.f, -2.f), always = make_float4(0.f, 0.f, 0.f, 2.f);
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 l1 = never, a = z4, b = z4, c = z4;
     // L1s[i] = sine of the cone's (inflated) half angle, used by the packet search's beam test:
     // 0 for "always", -inf for "never" (which turns cos(theta + beta) into +inf or NaN: no survivor)
     float sin_t = -__builtin_inff();
-    if (i >= 0) { // i = the primitive, -1 = padding
+    {
         int obj = s.prim_obj[i], tri = s.prim_tri[i];
         d3 ctr; double rad; bool sphere_like = false;
         if (tri < 0) {
@@ -230,6 +227,7 @@ struct Bundle {
     d3 e1, e2;    // kind 2: basis of the projection plane
     d3 dir;       // kind 2: the common ray direction (unit)
     double rmaxp; // kind 2: upper bound of (bounding radius + per-primitive rounding bound)
+    int eye;      // kind 1: the bundle of the camera rays (its origin is every ray's exact origin)
     int binned;   // packet search: the rays of this bundle are also counted into direction bins
     float plane_extent; // kind 2: half-width of the binning grid on the projection plane
 };
@@ -246,7 +244,7 @@ __device__ __forceinline__ TableRow bundle_direction_row(const SceneView &s, con
     float4 never = make_float4(0.f, 0.f, -inf, __builtin_nanf("")), always = make_float4(0.f, 0.f, inf, inf);
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 l1 = never, a = z4, b = z4, c = z4;
-    if (i >= 0) { // i = the primitive, -1 = padding
+    {
         int obj = s.prim_obj[i], tri = s.prim_tri[i];
         d3 ctr; double rad = 0; bool round_like = false;
         if (tri < 0) {
@@ -360,56 +358,6 @@ __device__ __forceinline__ Bound bound_of_wave(int kind, float4 p, float st) {
     if (!(R < 1e30)) { out.p.z = inf; out.p.w = inf; return out; }
     out.p = make_float4((float)cx, (float)cy, (float)(R * R * (1.0 + 1e-6)), (float)(R * (1.0 + 1e-6)));
     return out;
-}
-
-// The tables of one bundle (one workspace slot).  n_table = 4096 * superchunks >= the padded
-// primitive count; chunk c = rows 64 c .. 64 c + 63, superchunk s = chunks 64 s .. 64 s + 63.
-struct Tables {
-    float4 *L1;  float *L1s;  // [n_table] primitive bounds (L1s: sine of the cone's half angle, kind 1)
-    float4 *L2;               // [3 n_table] pyramid / edge rows; row 0 .w = candidate id
-    float4 *C1;  float *C1s;  // [n_table / 64] chunk bounds
-    float4 *S1;  float *S1s;  // [top_stride] superchunk bounds, padded to whole wave loads with "never"
-    int32_t n_table, top_stride;
-};
-__device__ __forceinline__ Tables slot_tables(const Tables &t, size_t g) {
-    Tables o = t;
-    o.L1 += g * t.n_table; o.L1s += g * t.n_table; o.L2 += 3 * g * t.n_table;
-    o.C1 += g * (t.n_table / 64); o.C1s += g * (t.n_table / 64);
-    o.S1 += g * t.top_stride; o.S1s += g * t.top_stride;
-    return o;
-}
-
-// rows and chunk bounds of one bundle: thread = table position, wave = chunk
-__device__ __forceinline__ void write_rows(const SceneView &s, const Bundle &bd, int is_eye, const Tables &t) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x; // < n_table (the grid covers it exactly)
-    const int prim = table_prim(s, i);
-    const TableRow row = (bd.kind == 1) ? bundle_origin_row(s, bd.o, is_eye, prim) : bundle_direction_row(s, bd, prim);
-    t.L1[i] = row.l1;
-    t.L1s[i] = row.sin_t;
-    t.L2[3 * (size_t)i] = row.a; t.L2[3 * (size_t)i + 1] = row.b; t.L2[3 * (size_t)i + 2] = row.c;
-    const Bound bnd = bound_of_wave(bd.kind, row.l1, row.sin_t);
-    if ((threadIdx.x & 63) == 0) { t.C1[i / 64] = bnd.p; t.C1s[i / 64] = bnd.s; }
-}
-// table of the camera rays' bundle (slot 0)
-__global__ __launch_bounds__(256) void k_bundle_eye(SceneView s, Bundle bd, Tables t) { write_rows(s, bd, 1, t); }
-// tables of the shadow-ray bundles of a group of lights, slot = blockIdx.y
-__global__ __launch_bounds__(256) void k_bundle_group(SceneView s, Group gr, Tables t) {
-    const Bundle &bd = gr.b[blockIdx.y];
-    if (bd.kind) write_rows(s, bd, 0, slot_tables(t, blockIdx.y));
-}
-// superchunk bounds from the chunk bounds: thread = chunk, wave = superchunk; slot = blockIdx.y.
-// The grid covers top_stride * 64 chunks; those past the table are "never".
-__global__ __launch_bounds__(256) void k_bundle_up(Group gr, Tables t_all) {
-    const int g = blockIdx.y;
-    const int kind = gr.b[g].kind;
-    if (!kind) return;
-    const Tables t = slot_tables(t_all, g);
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    float4 p = (kind == 1) ? make_float4(0.f, 0.f, 0.f, -2.f) : make_float4(0.f, 0.f, -__builtin_inff(), __builtin_nanf(""));
-    float st = (kind == 1) ? -__builtin_inff() : 0.f;
-    if (c < t.n_table / 64) { p = t.C1[c]; st = t.C1s[c]; }
-    const Bound bnd = bound_of_wave(kind, p, st);
-    if ((threadIdx.x & 63) == 0) { t.S1[c / 64] = bnd.p; t.S1s[c / 64] = bnd.s; }
 }
 
 // fp32 search record of a shadow ray for the given bundle
@@ -679,6 +627,126 @@ __global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist_
     if (t == 1023) hist[HIST_TOTAL] = total;
 }
 
+// ---- the tables of a bundle ----------------------------------------------------------------------------
+// One set per table slot.  Rows are laid out by WHERE THE PRIMITIVE LIES AS SEEN FROM THE BUNDLE: a
+// counting sort on the same 128x128 Hilbert-ordered grid the rays use (octahedral map of the cone
+// axis, or the projection plane), cell 0 reserved for the "always" records; primitives that can never
+// be hit by the bundle get no row at all.  So the 64 rows of a chunk, and the 64 chunks of a
+// superchunk, are neighbours in direction and their common bound is tight, whatever their depth.
+// Order inside a cell is whatever the atomics give; nothing downstream depends on row order.
+// n_table = 4096 * superchunks >= the padded primitive count; rows past the live ones are "never".
+#define TB_CELLS 17408 /* 1 + 16384 cells, rounded up to 1024 * 17 */
+struct Tables {
+    float4 *L1;  float *L1s;  // [n_table] primitive bounds (L1s: sine of the cone's half angle, kind 1)
+    float4 *L2;               // [3 n_table] pyramid / edge rows; row 0 .w = candidate id
+    float4 *C1;  float *C1s;  // [n_table / 64] chunk bounds
+    float4 *S1;  float *S1s;  // [top_stride] superchunk bounds, padded to whole wave loads with "never"
+    uint32_t *hist;           // [TB_CELLS + 1] rows per cell, then their offsets; [TB_CELLS] = live rows
+    uint32_t *cell, *rank;    // [n_prims_pad] cell of every primitive (0xffffffff = no row) and its rank there
+    int32_t n_table, top_stride, n_prims_pad;
+};
+__device__ __forceinline__ Tables slot_tables(const Tables &t, size_t g) {
+    Tables o = t;
+    o.L1 += g * t.n_table; o.L1s += g * t.n_table; o.L2 += 3 * g * t.n_table;
+    o.C1 += g * (t.n_table / 64); o.C1s += g * (t.n_table / 64);
+    o.S1 += g * t.top_stride; o.S1s += g * t.top_stride;
+    o.hist += g * (TB_CELLS + 1); o.cell += g * t.n_prims_pad; o.rank += g * t.n_prims_pad;
+    return o;
+}
+// which table slot each bundle of a launch uses (blockIdx.y -> table slot)
+struct TableMap { int32_t slot[LIGHT_GROUP]; };
+
+__device__ __forceinline__ TableRow bundle_row(const SceneView &s, const Bundle &bd, int prim) {
+    return (bd.kind == 1) ? bundle_origin_row(s, bd.o, bd.eye, prim) : bundle_direction_row(s, bd, prim);
+}
+// step 1: cell and rank of every primitive; thread = primitive, bundle = blockIdx.y
+__global__ __launch_bounds__(256) void k_table_bin(SceneView s, Group gr, TableMap tm, Tables t_all) {
+    const Bundle &bd = gr.b[blockIdx.y];
+    if (!bd.kind) return;
+    const Tables t = slot_tables(t_all, tm.slot[blockIdx.y]);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cell = 0xffffffffu;
+    if (i < s.n_prims) {
+        const TableRow row = bundle_row(s, bd, i);
+        const bool never = (bd.kind == 1) ? (row.l1.w <= -1.5f) : !(row.l1.w == row.l1.w);
+        const bool always = (bd.kind == 1) ? (row.l1.w >= 1.5f) : (row.l1.w == __builtin_inff());
+        if (always) cell = 0u;
+        else if (!never) cell = 1u + ray_bin(bd.kind, row.l1, bd.plane_extent);
+    }
+    uint32_t rank, leader;
+    const uint32_t before = wave_bin_count(t.hist, cell, cell != 0xffffffffu, rank, leader);
+    const uint32_t base = (uint32_t)__shfl((int)before, (int)leader, 64);
+    if (i < s.n_prims) { t.cell[i] = cell; t.rank[i] = base + rank; }
+}
+// step 2: counts -> offsets (one workgroup per bundle)
+__global__ __launch_bounds__(1024) void k_table_scan(Group gr, TableMap tm, Tables t_all) {
+    if (!gr.b[blockIdx.x].kind) return;
+    const Tables t = slot_tables(t_all, tm.slot[blockIdx.x]);
+    __shared__ uint32_t part[1024];
+    constexpr int PER = TB_CELLS / 1024;
+    const int c = threadIdx.x;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { v[k] = t.hist[c * PER + k]; sum += v[k]; }
+    part[c] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t x = (c >= off) ? part[c - off] : 0u;
+        __syncthreads();
+        part[c] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[c] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { t.hist[c * PER + k] = run; run += v[k]; }
+    if (c == 1023) t.hist[TB_CELLS] = part[1023];
+}
+// step 3: the rows, each at its cell's offset + its rank; thread = primitive
+__global__ __launch_bounds__(256) void k_table_rows(SceneView s, Group gr, TableMap tm, Tables t_all) {
+    const Bundle &bd = gr.b[blockIdx.y];
+    if (!bd.kind) return;
+    const Tables t = slot_tables(t_all, tm.slot[blockIdx.y]);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n_prims) return;
+    const uint32_t cell = t.cell[i];
+    if (cell == 0xffffffffu) return;
+    const TableRow row = bundle_row(s, bd, i);
+    const size_t at = (size_t)t.hist[cell] + t.rank[i];
+    t.L1[at] = row.l1;
+    t.L1s[at] = row.sin_t;
+    t.L2[3 * at] = row.a; t.L2[3 * at + 1] = row.b; t.L2[3 * at + 2] = row.c;
+}
+// step 4: chunk bounds; rows past the live ones become "never".  thread = row, wave = chunk
+__global__ __launch_bounds__(256) void k_table_chunks(Group gr, TableMap tm, Tables t_all) {
+    const int kind = gr.b[blockIdx.y].kind;
+    if (!kind) return;
+    const Tables t = slot_tables(t_all, tm.slot[blockIdx.y]);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // < n_table (the grid covers it exactly)
+    float4 p; float st;
+    if ((uint32_t)i < t.hist[TB_CELLS]) {
+        p = t.L1[i]; st = t.L1s[i];
+    } else {
+        p = (kind == 1) ? make_float4(0.f, 0.f, 0.f, -2.f) : make_float4(0.f, 0.f, -__builtin_inff(), __builtin_nanf(""));
+        st = (kind == 1) ? -__builtin_inff() : 0.f;
+        t.L1[i] = p; t.L1s[i] = st;
+    }
+    const Bound bnd = bound_of_wave(kind, p, st);
+    if ((threadIdx.x & 63) == 0) { t.C1[i / 64] = bnd.p; t.C1s[i / 64] = bnd.s; }
+}
+// step 5: superchunk bounds from the chunk bounds: thread = chunk, wave = superchunk.  The grid covers
+// top_stride * 64 chunks; those past the table are "never".
+__global__ __launch_bounds__(256) void k_table_supers(Group gr, TableMap tm, Tables t_all) {
+    const int kind = gr.b[blockIdx.y].kind;
+    if (!kind) return;
+    const Tables t = slot_tables(t_all, tm.slot[blockIdx.y]);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 p = (kind == 1) ? make_float4(0.f, 0.f, 0.f, -2.f) : make_float4(0.f, 0.f, -__builtin_inff(), __builtin_nanf(""));
+    float st = (kind == 1) ? -__builtin_inff() : 0.f;
+    if (c < t.n_table / 64) { p = t.C1[c]; st = t.C1s[c]; }
+    const Bound bnd = bound_of_wave(kind, p, st);
+    if ((threadIdx.x & 63) == 0) { t.S1[c / 64] = bnd.p; t.S1s[c / 64] = bnd.s; }
+}
+
 // ---- the all-pairs candidate search ------------------------------------------------------------------
 // One workgroup = one 32x32 pixel tile, 4 rays per lane.  The primitive stream is staged through
 // LDS in tiles of 512 cones (double buffered, one barrier per tile); every lane reads the same
@@ -745,7 +813,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
                                                            uint32_t list_stride, uint32_t n_active_stride) {
     // the slot of this launch row: its table, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
-    const Tables tb = slot_tables(t_all, g);
+    const Tables tb = slot_tables(t_all, (size_t)sl.table[blockIdx.y]);
     const float4 *__restrict__ L1 = tb.L1, *__restrict__ L2 = tb.L2;
     const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
@@ -770,7 +838,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
         rx[r] = q.x; ry[r] = q.y; rz[r] = q.z; rw[r] = q.w; cnt[r] = 0;
         if (KIND == 2) floor_lane = fminf(floor_lane, -q.z);
     }
-    const int n_tiles = n_padded / PRIM_TILE;
+    const int n_tiles = max(1, min(n_padded, (int)tb.hist[TB_CELLS] + PRIM_TILE - 1) / PRIM_TILE); // live rows only
     float4 s0 = L1[t], s1 = L1[t + SEARCH_THREADS];
     lds[0][t] = s0; lds[0][t + SEARCH_THREADS] = s1;
     __syncthreads();
@@ -861,7 +929,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                                                                   uint32_t list_stride, uint32_t n_active_stride) {
     // the slot of this launch row: its tables, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
-    const Tables tb = slot_tables(t_all, g);
+    const Tables tb = slot_tables(t_all, (size_t)sl.table[blockIdx.y]);
     const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
@@ -947,12 +1015,18 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     };
 
     uint32_t n_surv = 0;
+#ifdef RT355_DEBUG_SURVIVORS
+    uint32_t dbg_super = 0, dbg_chunk = 0;
+#endif
     const int n_super = tb.n_table / 4096;
     for (int top = 0; top * 64 < n_super; top++) {
         // ---- 64 superchunk bounds
         const float4 e2 = tb.S1[top * 64 + lane];
         const float e2s = (KIND == 1) ? tb.S1s[top * 64 + lane] : 0.f;
         unsigned long long m_super = __ballot(meets(e2, e2s));
+#ifdef RT355_DEBUG_SURVIVORS
+        dbg_super += (uint32_t)__popcll(m_super);
+#endif
         float4 nq; float nqs = 0.f; // chunk bounds of the next surviving superchunk, in flight
         auto fetch_super = [&](int sc) {
             nq = tb.C1[(size_t)sc * 64 + lane];
@@ -967,6 +1041,9 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
             if (m_super) { s_next = top * 64 + __builtin_ctzll(m_super); fetch_super(s_next); }
             // ---- the 64 chunk bounds of superchunk sc
             unsigned long long m_chunk = __ballot(meets(e1, e1s));
+#ifdef RT355_DEBUG_SURVIVORS
+            dbg_chunk += (uint32_t)__popcll(m_chunk);
+#endif
             float4 np, na, nb, nc; float nst = 0.f; // rows of the next surviving chunk, in flight
             auto fetch_chunk = [&](int c) {
                 const size_t at = ((size_t)sc * 64 + c) * 64 + lane;
@@ -1021,13 +1098,15 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
         if (live[r]) cand_cnt[rid[r]] = cnt[r];
     if (lane == 0 && n_surv) {
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
-#ifdef RT355_DEBUG_SURVIVORS
-        atomicMax(&counters[8], (unsigned long long)n_surv);
-        if (n_surv > 256) atomicAdd(&counters[9], 1ull);
-        if (n_surv > 1024) atomicAdd(&counters[10], 1ull);
-        if (n_surv > 4096) atomicAdd(&counters[11], 1ull);
-#endif
     }
+#ifdef RT355_DEBUG_SURVIVORS
+    if (lane == 0) {
+        atomicMax(&counters[8], (unsigned long long)n_surv);
+        atomicAdd(&counters[9], 1ull);
+        atomicAdd(&counters[10], (unsigned long long)dbg_super);
+        atomicAdd(&counters[11], (unsigned long long)dbg_chunk);
+    }
+#endif
 }
 
 // ---- fp64 closest hit over a ray's candidates (or over everything) -----------------------------------
@@ -1378,7 +1457,8 @@ struct rt355_scene {
     // owned device allocations of the scene
     std::vector<void *> owned;
     // per-render bundle tables and per-ray workspace (grown on demand)
-    Tables tables{};   // one set per workspace slot
+    Tables tables{};   // one set per table slot: the lights of a group, then the camera rays
+    std::vector<Bundle> built; // the bundle each table slot currently holds (kind 0 = none)
     int n_table = 0;   // table rows per slot: whole superchunks (multiples of 4096) >= n_padded
     Work work{};
     uint32_t work_rays = 0;
@@ -1485,55 +1565,12 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         tex[i].offset = pool.size(); tex[i].sx = t.sx; tex[i].sy = t.sy; tex[i].width = t.width; tex[i].height = t.height;
         pool.insert(pool.end(), t.rgb, t.rgb + (size_t)t.width * t.height * 3);
     }
-    // Search-table order: primitives sorted along a Morton curve through their centres (planes, which no
-    // cone or circle bounds, first), so that table neighbours are neighbours in space.
-    std::vector<int32_t> order(prim_obj.size());
-    {
-        const size_t np = prim_obj.size();
-        std::vector<h3> ctr(np);
-        std::vector<char> finite(np, 0);
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (size_t i = 0; i < np; i++) {
-            if (prim_tri[i] >= 0) { ctr[i] = H3(tris[prim_tri[i]].p_center); finite[i] = 1; }
-            else if (objs[prim_obj[i]].type == RT355_OBJ_SPHERE) { ctr[i] = H3(objs[prim_obj[i]].p); finite[i] = 1; }
-            const double v[3] = {ctr[i].x, ctr[i].y, ctr[i].z};
-            if (finite[i] && std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2])) {
-                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], v[a]); hi[a] = std::max(hi[a], v[a]); }
-            } else {
-                finite[i] = 0;
-            }
-        }
-        auto spread = [](uint64_t v) { // 21 bits -> every third bit
-            v &= 0x1fffffull;
-            v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
-            v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-            v = (v | v << 2) & 0x1249249249249249ull;
-            return v;
-        };
-        std::vector<std::pair<uint64_t, int32_t>> keyed(np);
-        for (size_t i = 0; i < np; i++) {
-            uint64_t key = 0;
-            if (finite[i]) {
-                const double v[3] = {ctr[i].x, ctr[i].y, ctr[i].z};
-                uint64_t q[3];
-                for (int a = 0; a < 3; a++) {
-                    const double span = hi[a] - lo[a];
-                    const double u = span > 0 ? (v[a] - lo[a]) / span : 0.0;
-                    q[a] = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
-                }
-                key = 1 + (spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2);
-            }
-            keyed[i] = {key, (int32_t)i};
-        }
-        std::sort(keyed.begin(), keyed.end());
-        for (size_t i = 0; i < np; i++) order[i] = keyed[i].second;
-    }
     rt355_scene *sc = new rt355_scene();
     HIP_TRY(hipGetDevice(&sc->device));
     int rc;
     if ((rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
         (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
-        (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || (rc = upload(sc, order, &sc->view.order)) ||
+        (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || 
         (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels))) {
         rt355_scene_destroy(sc);
         return rc;
@@ -1545,6 +1582,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->n_table = (sc->n_padded + 4095) / 4096 * 4096;
     sc->tables.n_table = sc->n_table;
     sc->tables.top_stride = (sc->n_table / 4096 + 63) / 64 * 64;
+    sc->tables.n_prims_pad = std::max(256, (sc->view.n_prims + 255) / 256 * 256);
     sc->has_tris = d->n_triangles > 0;
     sc->rmax = rmax; sc->extent = extent;
     HIP_TRY(hipEventCreate(&sc->ev_begin));
@@ -1559,12 +1597,13 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
 
 static void free_tables(rt355_scene *sc) {
     Tables &t = sc->tables;
-    void *ps[] = {t.L1, t.L1s, t.L2, t.C1, t.C1s, t.S1, t.S1s};
+    void *ps[] = {t.L1, t.L1s, t.L2, t.C1, t.C1s, t.S1, t.S1s, t.hist, t.cell, t.rank};
     for (void *p : ps) if (p) (void)hipFree(p);
-    const int n_table = t.n_table, top_stride = t.top_stride;
+    const int n_table = t.n_table, top_stride = t.top_stride, n_prims_pad = t.n_prims_pad;
     t = Tables{};
-    t.n_table = n_table; t.top_stride = top_stride;
+    t.n_table = n_table; t.top_stride = top_stride; t.n_prims_pad = n_prims_pad;
     sc->table_slots = 0;
+    sc->built.clear();
 }
 
 static void free_work(rt355_scene *sc) {
@@ -1606,10 +1645,14 @@ static int slots_for(uint32_t n_rays, int n_lights) {
 }
 
 static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundles, int n_groups) {
-    if (slots > sc->table_slots) { // one set of bundle tables per slot
+    if (slots + 1 > sc->table_slots) { // one set of bundle tables per light in flight + one for the camera rays
         free_tables(sc);
         Tables &t = sc->tables;
-        const size_t rows = (size_t)slots * t.n_table, chunks = rows / 64, tops = (size_t)slots * t.top_stride;
+        const size_t sets = (size_t)slots + 1;
+        const size_t rows = sets * t.n_table, chunks = rows / 64, tops = sets * t.top_stride;
+        HIP_TRY(hipMalloc((void **)&t.hist, sets * (TB_CELLS + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&t.cell, sets * t.n_prims_pad * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&t.rank, sets * t.n_prims_pad * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **)&t.L1, rows * sizeof(float4)));
         HIP_TRY(hipMalloc((void **)&t.L1s, rows * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&t.L2, rows * 3 * sizeof(float4)));
@@ -1617,7 +1660,10 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
         HIP_TRY(hipMalloc((void **)&t.C1s, chunks * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&t.S1, tops * sizeof(float4)));
         HIP_TRY(hipMalloc((void **)&t.S1s, tops * sizeof(float)));
-        sc->table_slots = slots;
+        sc->table_slots = slots + 1;
+        Bundle none;
+        memset(&none, 0, sizeof none);
+        sc->built.assign(sets, none);
     }
     while ((int)sc->ev_search.size() < 2 * n_bundles) {
         hipEvent_t e;
@@ -1732,6 +1778,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     for (auto &b : bundles) memset(&b, 0, sizeof b);
     if (can_search) {
         bundles[0].kind = 1;
+        bundles[0].eye = 1;
         bundles[0].o.x = dc.p_eye[0]; bundles[0].o.y = dc.p_eye[1]; bundles[0].o.z = dc.p_eye[2];
         for (int k = 0; k < nl; k++) {
             Bundle &b = bundles[1 + k];
@@ -1747,6 +1794,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
                 b.kind = 2;
                 b.e1.x = e1.x; b.e1.y = e1.y; b.e1.z = e1.z; b.e2.x = e2.x; b.e2.y = e2.y; b.e2.z = e2.z;
                 b.rmaxp = sc->rmax * (1.0 + 1e-6) + 8.0 * 2.384185791015625e-07 * (sc->extent + sc->rmax) + 1e-30;
+                b.plane_extent = (float)(2.0 * (sc->extent + sc->rmax) + 1.0);
                 b.dir.x = w.x; b.dir.y = w.y; b.dir.z = w.z;
             }
         }
@@ -1754,10 +1802,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
 
     if (opts->mode == RT355_MODE_PACKET)
         for (int k = 0; k < nl; k++)
-            if (bundles[1 + k].kind) {
-                bundles[1 + k].binned = 1;
-                bundles[1 + k].plane_extent = (float)(2.0 * (sc->extent + sc->rmax) + 1.0);
-            }
+            if (bundles[1 + k].kind) bundles[1 + k].binned = 1;
 
     HIP_TRY(hipEventRecord(sc->ev_begin, st));
     HIP_TRY(hipMemsetAsync(sc->work.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
@@ -1791,18 +1836,45 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         launches++;
         return RT355_OK;
     };
+    // (Re)build the tables of the bundles of `gr` in the table slots `tm` names; a slot that already holds
+    // the same bundle (same light as in the last frame; the scene never changes) is left alone.
+    const unsigned prim_blocks = (unsigned)std::max(1, (sc->view.n_prims + 255) / 256);
+    auto build_tables = [&](const Group &gr, const TableMap &tm) -> int {
+        Group todo = gr;
+        bool any = false;
+        for (int g = 0; g < gr.count; g++) {
+            Bundle &have = sc->built[tm.slot[g]];
+            if (!gr.b[g].kind || memcmp(&have, &gr.b[g], sizeof(Bundle)) == 0) { todo.b[g].kind = 0; continue; }
+            have = gr.b[g];
+            any = true;
+            HIP_TRY(hipMemsetAsync(sc->tables.hist + (size_t)tm.slot[g] * (TB_CELLS + 1), 0, (TB_CELLS + 1) * sizeof(uint32_t), st));
+        }
+        if (!any) return RT355_OK;
+        const unsigned ny = (unsigned)gr.count;
+        hipLaunchKernelGGL(k_table_bin, dim3(prim_blocks, ny), dim3(256), 0, st, sc->view, todo, tm, sc->tables);
+        hipLaunchKernelGGL(k_table_scan, dim3(ny), dim3(1024), 0, st, todo, tm, sc->tables);
+        hipLaunchKernelGGL(k_table_rows, dim3(prim_blocks, ny), dim3(256), 0, st, sc->view, todo, tm, sc->tables);
+        hipLaunchKernelGGL(k_table_chunks, dim3(table_blocks, ny), dim3(256), 0, st, todo, tm, sc->tables);
+        hipLaunchKernelGGL(k_table_supers, dim3(top_blocks, ny), dim3(256), 0, st, todo, tm, sc->tables);
+        return RT355_OK;
+    };
     // tables, ray lists and searches of all the lights of a group: one launch per step, slot = blockIdx.y
     auto search_group = [&](const Group &gr) -> int {
         Slots searched{}, of_kind[3]{};
-        for (int g = 0; g < gr.count; g++)
+        TableMap tm{};
+        for (int g = 0; g < gr.count; g++) {
+            tm.slot[g] = g; // light k0 + g: workspace slot g, table slot g
             if (gr.b[g].kind) {
+                searched.table[searched.count] = g;
                 searched.slot[searched.count++] = g;
                 Slots &k = of_kind[gr.b[g].kind];
+                k.table[k.count] = g;
                 k.slot[k.count++] = g;
             }
+        }
         if (!searched.count) return RT355_OK;
-        hipLaunchKernelGGL(k_bundle_group, dim3(table_blocks, (unsigned)gr.count), dim3(256), 0, st, sc->view, gr, sc->tables);
-        hipLaunchKernelGGL(k_bundle_up, dim3(top_blocks, (unsigned)gr.count), dim3(256), 0, st, gr, sc->tables);
+        int rc1 = build_tables(gr, tm);
+        if (rc1) return rc1;
         const uint32_t *total; uint32_t total_stride;
         if (opts->mode == RT355_MODE_PACKET) { // the producer of the rays counted them into direction bins: order them
             hipLaunchKernelGGL(k_scan_bins, dim3((unsigned)searched.count), dim3(1024), 0, st, w.bin_hist, w.active_rid, w.list_stride, searched);
@@ -1837,14 +1909,17 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         return RT355_OK;
     };
     if (bundles[0].kind) {
+        // camera rays: workspace slot 0, the last table slot (so that the lights' tables survive the frame)
         Slots eye{};
         eye.count = 1;
+        eye.table[0] = sc->table_slots - 1;
         hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, w.ray32);
         Group eye_group;
         memset(&eye_group, 0, sizeof eye_group);
         eye_group.count = 1; eye_group.b[0] = bundles[0];
-        hipLaunchKernelGGL(k_bundle_eye, dim3(table_blocks), dim3(256), 0, st, sc->view, bundles[0], sc->tables);
-        hipLaunchKernelGGL(k_bundle_up, dim3(top_blocks, 1), dim3(256), 0, st, eye_group, sc->tables);
+        TableMap eye_map{};
+        eye_map.slot[0] = sc->table_slots - 1;
+        if ((rc = build_tables(eye_group, eye_map))) return rc;
         if ((rc = launch_search(1, eye, nullptr, nullptr, 0))) return rc;
     }
     Group cur = group_of(0);
@@ -1913,7 +1988,9 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->packet_survivors = ctr[3];
         s->primary_hits = ctr[4];
 #ifdef RT355_DEBUG_SURVIVORS
-        fprintf(stderr, "[rt355] survivors: total %llu max/wave %llu waves>256 %llu >1024 %llu >4096 %llu\n", ctr[3], shards[8], shards[9], shards[10], shards[11]);
+        fprintf(stderr, "[rt355] packet search: %llu waves, per wave %.2f superchunks, %.2f chunks, %.2f primitives met (max %llu)\n",
+                shards[9], (double)shards[10] / (double)std::max(1ull, shards[9]), (double)shards[11] / (double)std::max(1ull, shards[9]),
+                (double)ctr[3] / (double)std::max(1ull, shards[9]), shards[8]);
 #endif
     }
     return RT355_OK;

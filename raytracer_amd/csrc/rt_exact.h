@@ -192,7 +192,6 @@ struct SceneView { // device pointers of an uploaded scene
     const DTriangle *tris;
     const int32_t *prim_obj;   // primitive -> object index
     const int32_t *prim_tri;   // primitive -> triangle index, or -1 for a plane / sphere
-    const int32_t *order;      // search-table position -> primitive (primitives along a space-filling curve)
     const double4 *prim_rec;   // primitive -> 32-byte record for the candidate tests: a sphere's centre and
                                // radius; for a triangle or plane the first 8 bytes hold (object, triangle)
     const DTexture *textures;
