@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -40,14 +41,15 @@
 #define TILE_W 32                       // tile width in pixels; one workgroup searches one tile
 #define TILE_H (8 * RAYS_PER_THREAD)    // tile height in pixels
 #define RAYS_PER_TILE (SEARCH_THREADS * RAYS_PER_THREAD)
-#ifndef PACKET_RAYS
-#define PACKET_RAYS 4 // rays per lane of the packet search: a multiple of RAYS_PER_THREAD
-#endif
+// The packet search is compiled for 4 rays per lane (256-ray waves: fewer table walks per ray) and for 1
+// (64-ray waves: narrower beams and four times as many waves to share a region where beams graze a
+// surface and meet thousands of primitives).  Which one is faster depends on the scene and the bundle;
+// every scene handle times both on its first frames and keeps the faster one per kind of launch.
+#define PACKET_RAYS_MAX 4
 #ifndef PACKET_WAVES
 #define PACKET_WAVES 4 // waves per workgroup of the packet search
 #endif
 #define PACKET_THREADS (64 * PACKET_WAVES)
-#define PACKET_BLOCK_RAYS (PACKET_THREADS * PACKET_RAYS)
 #ifndef PRIM_TILE
 #define PRIM_TILE 512       // primitives staged in LDS per step (8 KiB, double buffered)
 #endif
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist_
     }
     __syncthreads();
     const uint32_t sum_c = part[t];
-    const uint32_t padded = (sum_c + (64u * PACKET_RAYS - 1u)) / (64u * PACKET_RAYS) * (64u * PACKET_RAYS);
+    const uint32_t padded = (sum_c + (64u * PACKET_RAYS_MAX - 1u)) / (64u * PACKET_RAYS_MAX) * (64u * PACKET_RAYS_MAX);
     __syncthreads();
     part[t] = padded;
     __syncthreads();
@@ -899,26 +901,36 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
 // handful per wave) get the per-ray test of k_search, with operands broadcast from registers.
 // Waves do not cooperate, so there is no barrier and no LDS; candidates come out in table order,
 // which the exact resolve does not depend on.
+// Wave-wide reductions: four DPP row rotations leave every lane of a 16-lane row with the row's
+// result, then the four rows are combined through scalar registers.  No LDS traffic (a __shfl_xor
+// butterfly is six ds_bpermute round trips).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+#define DPP_ROW_ROR(n) (0x120 + (n))
+__device__ __forceinline__ float row_get(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_f<DPP_ROW_ROR(8)>(v); v += dpp_f<DPP_ROW_ROR(4)>(v); v += dpp_f<DPP_ROW_ROR(2)>(v); v += dpp_f<DPP_ROW_ROR(1)>(v);
+    return (row_get(v, 0) + row_get(v, 16)) + (row_get(v, 32) + row_get(v, 48));
 }
 __device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fminf(v, dpp_f<DPP_ROW_ROR(8)>(v)); v = fminf(v, dpp_f<DPP_ROW_ROR(4)>(v));
+    v = fminf(v, dpp_f<DPP_ROW_ROR(2)>(v)); v = fminf(v, dpp_f<DPP_ROW_ROR(1)>(v));
+    return fminf(fminf(row_get(v, 0), row_get(v, 16)), fminf(row_get(v, 32), row_get(v, 48)));
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR(8)>(v)); v = fmaxf(v, dpp_f<DPP_ROW_ROR(4)>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR(2)>(v)); v = fmaxf(v, dpp_f<DPP_ROW_ROR(1)>(v));
+    return fmaxf(fmaxf(row_get(v, 0), row_get(v, 16)), fmaxf(row_get(v, 32), row_get(v, 48)));
 }
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-template <int KIND>
+template <int KIND, int PR>
 __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                                                                   const float4 *__restrict__ ray32_all, uint32_t n_rays,
                                                                   const uint32_t *__restrict__ active_rid_all,
@@ -936,20 +948,25 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t total = active_rid ? *n_active : n_rays;
-    if (blockIdx.x * PACKET_BLOCK_RAYS >= total) return;
-    float rx[PACKET_RAYS], ry[PACKET_RAYS], rz[PACKET_RAYS], rw[PACKET_RAYS];
-    uint32_t cnt[PACKET_RAYS], rid[PACKET_RAYS];
-    bool live[PACKET_RAYS];
+    if (blockIdx.x * (PACKET_THREADS * PR) >= total) return;
+    float rx[PR], ry[PR], rz[PR], rw[PR];
+    uint32_t cnt[PR], rid[PR];
+    bool live[PR];
     float sx = 0.f, sy = 0.f, sz = 0.f, nact = 0.f, msq_max = 0.f;
 #pragma unroll
-    for (int r = 0; r < PACKET_RAYS; r++) {
+    for (int r = 0; r < PR; r++) {
         uint32_t slot;
-        if (active_rid) { // sorted list: a wave takes 64*PACKET_RAYS consecutive entries
-            slot = blockIdx.x * PACKET_BLOCK_RAYS + wave * (64 * PACKET_RAYS) + r * 64 + lane;
-        } else {          // camera rays: quarter-waves of the screen tiling, numbered over the workgroup's tiles
-            const uint32_t q = wave * (PACKET_RAYS / RAYS_PER_THREAD) + (uint32_t)r / RAYS_PER_THREAD;
-            const uint32_t tile = blockIdx.x * (PACKET_WAVES * PACKET_RAYS / (4 * RAYS_PER_THREAD)) + q / 4;
-            slot = tile * RAYS_PER_TILE + ((uint32_t)r % RAYS_PER_THREAD) * SEARCH_THREADS + (q % 4) * 64 + lane;
+        if (active_rid) { // sorted list: a wave takes 64*PR consecutive entries
+            slot = blockIdx.x * (PACKET_THREADS * PR) + wave * (64 * PR) + r * 64 + lane;
+        } else {
+            // camera rays: ray r of the wave's lanes = one 8x8 pixel block (4x4 quads of a quarter tile, 16
+            // lanes per quad pixel, so a load touches 64-byte runs); 16 blocks per tile, a wave takes
+            // PR consecutive ones
+            const uint32_t blk = (blockIdx.x * PACKET_WAVES + wave) * PR + (uint32_t)r;
+            const uint32_t tile = blk / 16u, quarter = (blk / 4u) % 4u, qb = blk % 4u;
+            const uint32_t qi = lane & 15u, pix = lane >> 4;
+            const uint32_t quad = ((qb & 1u) * 4u + (qi & 3u)) + 8u * ((qb >> 1) * 4u + (qi >> 2));
+            slot = tile * RAYS_PER_TILE + pix * SEARCH_THREADS + quarter * 64u + quad;
         }
         live[r] = slot < total;
         rid[r] = active_rid ? (live[r] ? active_rid[slot] : 0xffffffffu) : slot;
@@ -966,7 +983,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     msq_max = wave_max_f(msq_max);
     if (!(nact > 0.f)) { // nothing to search for in this wave (uniform)
 #pragma unroll
-        for (int r = 0; r < PACKET_RAYS; r++) if (live[r]) cand_cnt[rid[r]] = 0;
+        for (int r = 0; r < PR; r++) if (live[r]) cand_cnt[rid[r]] = 0;
         return;
     }
     float wx, wy, wz = 0.f, w_cos = -1.f, w_sin = 0.f, w_rho = 0.f;
@@ -977,7 +994,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
         wx = sx * wi; wy = sy * wi; wz = sz * wi;
         float wlo = 1.f;
 #pragma unroll
-        for (int r = 0; r < PACKET_RAYS; r++)
+        for (int r = 0; r < PR; r++)
             if (rx[r] == rx[r]) wlo = fminf(wlo, __builtin_fmaf(rz[r], wz, __builtin_fmaf(ry[r], wy, rx[r] * wx)));
         const float w_spread = wave_min_f(wlo);
         w_all = !(wl2 > 1e-12f);
@@ -987,7 +1004,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
         wx = sx * wi; wy = sy * wi;
         float wfar = 0.f;
 #pragma unroll
-        for (int r = 0; r < PACKET_RAYS; r++)
+        for (int r = 0; r < PR; r++)
             if (rx[r] == rx[r]) {
                 const float du = rx[r] - wx, dv = ry[r] - wy;
                 wfar = fmaxf(wfar, __builtin_fmaf(du, du, dv * dv));
@@ -1065,10 +1082,10 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                     mask &= mask - 1ull;
                     float4 q;
                     q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
-                    bool hit[PACKET_RAYS];
+                    bool hit[PR];
                     bool any_hit = false;
 #pragma unroll
-                    for (int r = 0; r < PACKET_RAYS; r++) {
+                    for (int r = 0; r < PR; r++) {
                         hit[r] = pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f);
                         any_hit |= hit[r];
                     }
@@ -1082,11 +1099,11 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                         eb.x = lane_bcast(rb.x, i); eb.y = lane_bcast(rb.y, i); eb.z = lane_bcast(rb.z, i); eb.w = 0.f;
                         ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
 #pragma unroll
-                        for (int r = 0; r < PACKET_RAYS; r++)
+                        for (int r = 0; r < PR; r++)
                             if (hit[r]) append_rows<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < PACKET_RAYS; r++)
+                        for (int r = 0; r < PR; r++)
                             if (hit[r]) append_id(id, rid[r], n_rays, cand, cnt[r]);
                     }
                 }
@@ -1094,7 +1111,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
         }
     }
 #pragma unroll
-    for (int r = 0; r < PACKET_RAYS; r++)
+    for (int r = 0; r < PR; r++)
         if (live[r]) cand_cnt[rid[r]] = cnt[r];
     if (lane == 0 && n_surv) {
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
@@ -1473,6 +1490,12 @@ struct rt355_scene {
     int search_launches = 0;
     double search_ms = 0;
     std::vector<double> launch_ms, resolve_launch_ms;
+    // packet size per kind of search launch (0 camera rays, 1 lights with a position, 2 directional lights):
+    // best time seen with 4 and with 1 ray per lane (< 0 = not tried yet), and what each launch of the
+    // outstanding frame used
+    double tune_ms[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+    int forced_packet_rays = 0; // RT355_PACKET_RAYS=1|4 pins the choice (tests)
+    std::vector<std::pair<int, int>> launch_choice; // (kind of launch, rays per lane) per search launch
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
     uint64_t pending_primary = 0, pending_pairs_static = 0;
@@ -1579,6 +1602,10 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->view.n_prims = (int)prim_obj.size();
     sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
     if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
+    if (const char *e = getenv("RT355_PACKET_RAYS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 4) sc->forced_packet_rays = v;
+    }
     sc->n_table = (sc->n_padded + 4095) / 4096 * 4096;
     sc->tables.n_table = sc->n_table;
     sc->tables.top_stride = (sc->n_table / 4096 + 63) / 64 * 64;
@@ -1680,7 +1707,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
         // the slot strides follow the frame being rendered, not the capacity
         w.n = n_rays;
         w.tile_stride = n_rays / RAYS_PER_TILE + 1;
-        w.list_stride = n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS;
+        w.list_stride = n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX;
         return RT355_OK;
     }
     const uint32_t cap_rays = std::max(n_rays, sc->work_rays);
@@ -1696,7 +1723,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, g * CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, g * (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_hist, g * HIST_STRIDE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_id, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_rank, g * n * sizeof(uint32_t)));
@@ -1704,7 +1731,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     sc->work_slots = cap_slots;
     w.n = n_rays;
     w.tile_stride = n_rays / RAYS_PER_TILE + 1;
-    w.list_stride = n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS;
+    w.list_stride = n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX;
     return RT355_OK;
 }
 
@@ -1813,19 +1840,31 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     unsigned char *pix = (unsigned char *)d_pixmap;
     int launches = 0;
     const Work &w = sc->work;
-    const unsigned packet_eye_blocks = (unsigned)(((size_t)f.n_rays + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
-    const unsigned packet_list_blocks = (unsigned)(((size_t)w.list_stride + PACKET_BLOCK_RAYS - 1) / PACKET_BLOCK_RAYS);
+    sc->launch_choice.clear();
+    // rays per lane for a kind of launch: try 4, then 1, then keep the faster
+    auto packet_rays_for = [&](int cls) -> int {
+        if (sc->forced_packet_rays) return sc->forced_packet_rays;
+        if (sc->tune_ms[cls][0] < 0) return 4;
+        if (sc->tune_ms[cls][1] < 0) return 1;
+        return sc->tune_ms[cls][0] <= sc->tune_ms[cls][1] ? 4 : 1;
+    };
     // one search launch over the given slots (all of bundle kind `kind`); list / total = null for the camera rays
     auto launch_search = [&](int kind, const Slots &sl, const uint32_t *list, const uint32_t *total,
                              uint32_t total_stride) -> int {
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
-            const dim3 grid(list ? packet_list_blocks : packet_eye_blocks, (unsigned)sl.count);
-            if (kind == 1)
-                hipLaunchKernelGGL(k_search_packet<1>, grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
-            else
-                hipLaunchKernelGGL(k_search_packet<2>, grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride);
+            const int cls = list ? kind : 0, pr = packet_rays_for(cls);
+            sc->launch_choice.push_back({cls, pr});
+            const size_t n_entries = list ? (size_t)w.list_stride : (size_t)f.n_rays, per_block = (size_t)PACKET_THREADS * pr;
+            const dim3 grid((unsigned)((n_entries + per_block - 1) / per_block), (unsigned)sl.count);
+#define LAUNCH_PACKET(K, P) hipLaunchKernelGGL((k_search_packet<K, P>), grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride)
+            if (kind == 1 && pr == 4) LAUNCH_PACKET(1, 4);
+            else if (kind == 1) LAUNCH_PACKET(1, 1);
+            else if (pr == 4) LAUNCH_PACKET(2, 4);
+            else LAUNCH_PACKET(2, 1);
+#undef LAUNCH_PACKET
         } else {
+            sc->launch_choice.push_back({-1, 0});
             const dim3 grid(n_tiles, (unsigned)sl.count);
             if (kind == 1)
                 hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
@@ -1968,6 +2007,19 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         HIP_TRY(hipEventElapsedTime(&m, sc->ev_search[2 * i], sc->ev_search[2 * i + 1]));
         sc->search_ms += m;
         sc->launch_ms[i] = m;
+    }
+    { // what this frame's packet launches cost, per kind of launch (a frame can have several groups of lights)
+        double sum[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        bool used[3][2] = {{false, false}, {false, false}, {false, false}};
+        for (int i = 0; i < sc->search_launches && i < (int)sc->launch_choice.size(); i++) {
+            const int cls = sc->launch_choice[i].first, which = sc->launch_choice[i].second == 4 ? 0 : 1;
+            if (cls < 0) continue;
+            sum[cls][which] += sc->launch_ms[i];
+            used[cls][which] = true;
+        }
+        for (int c = 0; c < 3; c++)
+            for (int k = 0; k < 2; k++)
+                if (used[c][k]) sc->tune_ms[c][k] = sum[c][k];
     }
     sc->resolve_ms = 0;
     sc->resolve_launch_ms.assign(sc->resolve_launches, 0.0);

@@ -125,6 +125,32 @@ def test_more_lights_than_one_group(api, oracle, n_lights):
         r.close()
 
 
+@pytest.mark.parametrize("rays_per_lane", ["1", "4"])
+def test_packet_sizes_give_the_same_frames(api, oracle, monkeypatch, rays_per_lane):
+    """The packet search exists with 64-ray and 256-ray waves; a scene handle normally times both and keeps
+    the faster one.  Pinned to either, frames and candidate counts must not change."""
+    monkeypatch.setenv("RT355_PACKET_RAYS", rays_per_lane)
+    for name in ("spheres300", "spheres300_dir", "mesh", "mesh_dir", "textured"):
+        sc, sh, cam, w, h = S.small_case(name)
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+        r = api.Renderer(sc)
+        got, st = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
+        ref, rst = r.render(cam, sh, w, h, mode=B.MODE_ALLPAIRS)
+        r.close()
+        _compare(got, want)
+        assert st["exact_tests"] == rst["exact_tests"]
+
+
+def test_frames_do_not_change_while_the_packet_size_is_tuned(api):
+    """Frames 1 and 2 of a handle try the two packet sizes, later ones use the faster: same bytes throughout."""
+    sc, sh, cam, w, h = S.small_case("mesh_dir")
+    r = api.Renderer(sc)
+    frames = [r.render(cam, sh, w, h)[0] for _ in range(4)]
+    r.close()
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
+
+
 def test_orbit_cameras_mesh(api, oracle):
     """Other view points (the camera sweep): eye bundle tables are rebuilt per frame."""
     sc = S.mesh_scene(2000, seed=3, tex_size=32)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # One counter pass of the default bench run.  Usage (GPU box): bash tools/pmc_pass.sh <tag> <workload> COUNTER...
+# (RT355_LIB in the environment selects a library variant.)
 set -o pipefail
 tag=$1; wl=$2; shift 2
 cd "$GRAFT_REPO_ROOT" || exit 1
