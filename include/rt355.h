@@ -123,11 +123,42 @@ typedef struct rt355_shader {
 
 typedef struct rt355_opts {
     int32_t width, height; /* the reference's globals (main.cpp:33)                         */
-    int32_t alias;         /* setPixels' third argument; only 0 is accelerated so far       */
+    int32_t alias;         /* setPixels' third argument: 0 = one ray through the pixel corner
+                              (main.cpp:326-331), a > 0 = a x a jittered sub-samples per pixel,
+                              averaged (main.cpp:289-325), jitter from rt355_jitter below      */
     int32_t row_begin;     /* slab [row_begin,row_end) of rows to render; 0,0 = whole frame */
     int32_t row_end;
     int32_t mode;          /* RT355_MODE_*                                                  */
+    uint32_t seed;         /* alias > 0: seed of the jitter                                 */
+    int32_t reserved;      /* 0                                                             */
 } rt355_opts;
+
+/* The jitter of CalcPixel.  The reference draws `(double)rand() / RAND_MAX` twice per sub-sample
+ * (main.cpp:292-293) from libc's serial generator, in pixel order; that stream cannot be drawn in
+ * parallel and differs between C libraries.  rt355 keeps the value set (a 31-bit integer divided by
+ * RAND_MAX = 2147483647, so 0 <= jitter <= 1) and takes the integer from a counter-based generator
+ * instead (four rounds of the SplitMix64 finaliser over seed, x, y and 2 * sample + dim), so every
+ * sub-sample's jitter depends only on where it is.  sample = q * alias + p, dim 0 = x, 1 = y.
+ * Defined inline (rt355x_jitter) so that the library's device code, the CPU checker and the reference
+ * harness share one definition; the library also exports it as rt355_jitter for hosts in other languages. */
+#if defined(__HIPCC__)
+#define RT355_INLINE static __host__ __device__ inline
+#else
+#define RT355_INLINE static inline
+#endif
+RT355_INLINE uint64_t rt355x_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+RT355_INLINE double rt355x_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim) {
+    uint64_t z = rt355x_mix64((uint64_t)seed);
+    z = rt355x_mix64(z ^ (uint64_t)(uint32_t)x);
+    z = rt355x_mix64(z ^ (uint64_t)(uint32_t)y);
+    z = rt355x_mix64(z ^ (((uint64_t)(uint32_t)sample << 1) | (uint64_t)(dim & 1)));
+    return (double)(z >> 33) / 2147483647.0;
+}
 
 typedef struct rt355_stats {
     uint64_t primary_rays;   /* camera rays cast                                            */
@@ -190,6 +221,9 @@ int rt355_scene_search_launch_ms(rt355_scene *scene, int32_t index, double *ms);
 
 const char *rt355_last_error(void);
 int rt355_abi_version(void);
+
+/* rt355x_jitter as an exported function. */
+double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,19 @@ def main():
         frame = R.render(sc.pack(), cam, sh, B.opts(w, h))
         np.save(os.path.join(OUT, f"frame_{name}.npy"), frame)
         meta[name] = {"width": w, "height": h, "fnv1a64": f"{B.fnv1a64(frame):016x}"}
+    # 1b. supersampled frames (alias > 0): CalcPixel's sub-sample loop run with the reference's classes, the
+    #     jitter taken from rt355_jitter in place of rand()
+    meta["alias_cases"] = []
+    for name, alias in (("default_2lights", 2), ("textured", 3), ("mesh", 2), ("spheres300_dir", 3)):
+        sc, sh, cam, w, h = S.small_case(name)
+        w, h = w // 2, h // 2
+        cam = S.default_camera(w, h)
+        seed = 4000 + alias
+        frame = R.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=seed))
+        fn = f"frame_{name}_alias{alias}.npy"
+        np.save(os.path.join(OUT, fn), frame)
+        meta["alias_cases"].append({"case": name, "alias": alias, "seed": seed, "width": w, "height": h, "file": fn,
+                                    "fnv1a64": f"{B.fnv1a64(frame):016x}"})
     # 2. CalcIntersect known answers: rays aimed roughly at each object kind
     sc, _, _, _, _ = S.small_case("mesh")
     p = sc.pack()

@@ -196,10 +196,26 @@ int ref_render(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_s
     int W = opts->width, H = opts->height;
     int y0 = opts->row_begin, y1 = opts->row_end;
     if (y0 == 0 && y1 == 0) y1 = H;
+    const int alias = opts->alias;
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
-            View eye = calc_view(k, (double)x / W, (double)y / H);
-            Color c = sub_pixel(eye, rs.objs, shd);
+            Color c;
+            if (alias > 0) { // CalcPixel's sub-sample loop with the reference's Color; jitter from rt355_jitter, not rand()
+                double red = 0, green = 0, blue = 0;
+                for (int q = 0; q < alias; q++)
+                    for (int p = 0; p < alias; p++) {
+                        double pointX = (rt355x_jitter(opts->seed, x, y, q * alias + p, 0) + p) / alias + x;
+                        double pointY = (rt355x_jitter(opts->seed, x, y, q * alias + p, 1) + q) / alias + y;
+                        View eye = calc_view(k, pointX / W, pointY / H);
+                        Color clr_sub = sub_pixel(eye, rs.objs, shd);
+                        red += clr_sub.r; green += clr_sub.g; blue += clr_sub.b;
+                    }
+                red = red / (alias * alias); green = green / (alias * alias); blue = blue / (alias * alias);
+                c = Color(red, green, blue);
+            } else {
+                View eye = calc_view(k, (double)x / W, (double)y / H);
+                c = sub_pixel(eye, rs.objs, shd);
+            }
             size_t i = ((size_t)y * W + x) * 3;
             pixmap[i] = c.r; pixmap[i + 1] = c.g; pixmap[i + 2] = c.b;
         }

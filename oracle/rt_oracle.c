@@ -385,7 +385,10 @@ static int oscene_init(oscene *s, const rt355_scene_desc *d) {
 
 /* ---- exported entry points ------------------------------------------------------------------ */
 
-/* setPixels + CalcPixel with alias == 0, main.cpp:339-376, 326-332.
+/* setPixels + CalcPixel, main.cpp:339-376, 281-334: alias == 0 is the one ray of lines 326-332, alias > 0
+ * the alias x alias sub-samples of lines 289-325 with the jitter taken from rt355_jitter (see rt355.h) in
+ * place of rand(); the soft-shadow parameters m, n (lines 307-308) are not computed because
+ * Shader::shading does not use them (shader.h:90-91 calls CalcShadow).
  * `stride` > 1 renders only pixels with x % stride == 0 and y % stride == 0 (the rays
  * are the same as the full frame's; other pixels are left untouched) -- used to time a
  * bounded sample.  n_threads <= 0 = all cores; rows are interleaved over threads. */
@@ -393,7 +396,7 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
                      const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats,
                      int n_threads, int stride) {
     if (!d || !cam || !sh || !opts || !pixmap) return RT355_ERR_ARG;
-    if (opts->alias != 0) return RT355_ERR_UNSUPPORTED;
+    if (opts->alias < 0) return RT355_ERR_ARG;
     oscene s;
     if (oscene_init(&s, d)) return RT355_ERR_NOMEM;
     ocam c = set_camera(cam);
@@ -410,12 +413,29 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
     for (int y = y0; y < y1; y++) {
         if (y % stride) continue;
         octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0;
+        const int alias = opts->alias;
         for (int x = 0; x < W; x += stride) {
-            ray eye = calc_view(&c, (double)x / W, (double)y / H);
-            col clr = calc_subpixel(&cx, eye);
+            col clr;
+            if (alias > 0) {
+                double red = 0, green = 0, blue = 0;
+                for (int q = 0; q < alias; q++)
+                    for (int p = 0; p < alias; p++) {
+                        double pointX = (rt355x_jitter(opts->seed, x, y, q * alias + p, 0) + p) / alias + x; /* :292 */
+                        double pointY = (rt355x_jitter(opts->seed, x, y, q * alias + p, 1) + q) / alias + y; /* :293 */
+                        ray eye = calc_view(&c, pointX / W, pointY / H);
+                        col sub = calc_subpixel(&cx, eye);
+                        red += sub.r; green += sub.g; blue += sub.b;                                         /* :315-317 */
+                        prim++;
+                    }
+                red = red / (alias * alias); green = green / (alias * alias); blue = blue / (alias * alias);  /* :322-324 */
+                clr = C(q8(red), q8(green), q8(blue));                                                        /* :325 */
+            } else {
+                ray eye = calc_view(&c, (double)x / W, (double)y / H);
+                clr = calc_subpixel(&cx, eye);
+                prim++;
+            }
             size_t i = ((size_t)y * W + x) * 3;
             pixmap[i] = clr.r; pixmap[i + 1] = clr.g; pixmap[i + 2] = clr.b;
-            prim++;
         }
         shad += cx.shadow_rays;
     }
@@ -429,6 +449,11 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
 }
 
 /* Known-answer probes (one call = one reference function). */
+
+double rt_oracle_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim) {
+    return rt355x_jitter(seed, x, y, sample, dim);
+}
+
 
 /* Camera ray of pixel (x,y): out[0..2] = pe, out[3..5] = npe. */
 void rt_oracle_view(const rt355_camera *cam, int W, int H, int x, int y, double *out) {

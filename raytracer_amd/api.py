@@ -72,9 +72,9 @@ class Renderer:
             pass
 
     def render(self, cam, shader: Shader, width: int, height: int, alias=0, row_begin=0, row_end=0,
-               mode=MODE_PACKET, out: np.ndarray | None = None):
+               mode=MODE_PACKET, out: np.ndarray | None = None, seed=0):
         """Host framebuffer path (rt355_render).  Returns (pixmap (H,W,3) uint8, stats dict)."""
-        o = make_opts(width, height, alias, row_begin, row_end, mode)
+        o = make_opts(width, height, alias, row_begin, row_end, mode, seed)
         if out is None:
             out = np.zeros((height, width, 3), dtype=np.uint8)
         st = CStats()

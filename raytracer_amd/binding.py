@@ -64,7 +64,8 @@ class CShader(C.Structure):
 
 class COpts(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("alias", C.c_int32),
-                ("row_begin", C.c_int32), ("row_end", C.c_int32), ("mode", C.c_int32)]
+                ("row_begin", C.c_int32), ("row_end", C.c_int32), ("mode", C.c_int32),
+                ("seed", C.c_uint32), ("reserved", C.c_int32)]
 
 
 class CStats(C.Structure):
@@ -77,7 +78,7 @@ class CStats(C.Structure):
 
 
 assert C.sizeof(CTexture) == 32 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
-assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 24 and C.sizeof(CStats) == 64
+assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 32 and C.sizeof(CStats) == 64
 
 
 def _normalize(v: Sequence[float]):
@@ -240,8 +241,24 @@ def camera(p_eye=(0, -20, 0), v_view=(0, 1, 0), v_up=(0, 0, 1), dist=10.0, width
     return c
 
 
-def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_PACKET) -> COpts:
-    return COpts(width, height, alias, row_begin, row_end, mode)
+def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_PACKET, seed=0) -> COpts:
+    return COpts(width, height, alias, row_begin, row_end, mode, seed, 0)
+
+
+def jitter(seed, x, y, sample, dim) -> float:
+    """rt355_jitter of include/rt355.h (the jitter of CalcPixel, main.cpp:292-293, from a counter-based generator)."""
+    M = 0xFFFFFFFFFFFFFFFF
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    z = mix(seed & 0xFFFFFFFF)
+    z = mix(z ^ (x & 0xFFFFFFFF))
+    z = mix(z ^ (y & 0xFFFFFFFF))
+    z = mix(z ^ (((sample & 0xFFFFFFFF) << 1) | (dim & 1)))
+    return (z >> 33) / 2147483647.0
 
 
 def fnv1a64(buf) -> int:

@@ -33,7 +33,7 @@
 #include "../../include/rt355.h"
 #include "rt_exact.h"
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 #define SEARCH_THREADS 256
 #ifndef RAYS_PER_THREAD
 #define RAYS_PER_THREAD 4   // rays per lane of the search kernel (2, 4 or 8)
@@ -84,7 +84,21 @@ struct Frame {
     int32_t width, height, row_begin, rows; // rows of this slab
     int32_t tiles_x, tiles_y;
     uint32_t n_rays;                        // padded: tiles * 1024
+    // The grid the rays are numbered over: the pixels of the slab, or, with alias > 0, their sub-samples
+    // (sub-sample (p, q) of pixel (x, y) is grid point (x * alias + p, y * alias + q)).
+    int32_t grid_w, grid_h;
+    int32_t alias;
+    uint32_t seed;
 };
+// inverse of rid_to_xy
+__device__ __forceinline__ uint32_t xy_to_rid(int x, int y, int tiles_x) {
+    const uint32_t tile = (uint32_t)(y / TILE_H) * (uint32_t)tiles_x + (uint32_t)(x / TILE_W);
+    const uint32_t px = (uint32_t)(x % TILE_W), py = (uint32_t)(y % TILE_H);
+    const uint32_t wave = (px >> 4) | ((py / (8 * QUAD_H)) << 1);
+    const uint32_t lane = ((px >> 1) & 7u) | (((py % (8 * QUAD_H)) / QUAD_H) << 3);
+    const uint32_t r = (px & 1u) | ((py % QUAD_H) << 1);
+    return tile * RAYS_PER_TILE + r * 256u + wave * 64u + lane;
+}
 
 #define LIGHT_GROUP 8 // lights whose shadow rays and candidates are in flight together
 struct Work { // per-ray buffers, all indexed by rid (SoA)
@@ -372,14 +386,24 @@ __device__ __forceinline__ float4 bundle_ray(const Bundle &bd, d3 ph, d3 nhl) {
 }
 
 // ---- camera rays -------------------------------------------------------------------------------------
+// CalcPixel's ray for grid point (gx, gy): the pixel corner (main.cpp:327-329), or a jittered sub-sample
+// (main.cpp:292-303)
+__device__ __forceinline__ Ray grid_ray(const DCamera &cam, const Frame &f, int gx, int gy) {
+    if (f.alias <= 0)
+        return calc_view(cam, (double)gx / (double)f.width, (double)(gy + f.row_begin) / (double)f.height);
+    const int x = gx / f.alias, p = gx % f.alias, y = gy / f.alias + f.row_begin, q = gy % f.alias;
+    const double pointX = (rt355x_jitter(f.seed, x, y, q * f.alias + p, 0) + p) / f.alias + x;
+    const double pointY = (rt355x_jitter(f.seed, x, y, q * f.alias + p, 1) + q) / f.alias + y;
+    return calc_view(cam, pointX / (double)f.width, pointY / (double)f.height);
+}
 __global__ void k_gen_primary(DCamera cam, Frame f, float4 *__restrict__ ray32) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     if (rid >= f.n_rays) return;
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
     float4 out = nan4();
-    if (x < f.width && y < f.rows) {
-        Ray e = calc_view(cam, (double)x / (double)f.width, (double)(y + f.row_begin) / (double)f.height);
+    if (x < f.grid_w && y < f.grid_h) {
+        Ray e = grid_ray(cam, f, x, y);
         out = make_float4((float)e.npe.x, (float)e.npe.y, (float)e.npe.z, 0.f);
     }
     ray32[rid] = out;
@@ -1204,10 +1228,28 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
     evaluated += n;
 }
 
-__device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, const Frame &f, int x, int y,
-                                            uint32_t clr) {
+// the colour of grid point (x, y): a pixel of the frame, or a sub-sample kept for k_average
+__device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, const Frame &f, const Work &w,
+                                            uint32_t rid, int x, int y, uint32_t clr) {
+    if (f.alias > 0) { w.rec_sum[rid] = clr; return; }
     size_t i = ((size_t)(y + f.row_begin) * (size_t)f.width + (size_t)x) * 3;
     pixmap[i] = (unsigned char)cr(clr); pixmap[i + 1] = (unsigned char)cg(clr); pixmap[i + 2] = (unsigned char)cb(clr);
+}
+// CalcPixel's average over the alias x alias sub-samples of a pixel (main.cpp:315-325): sums of the
+// sub-samples' 8-bit channels in double, divided by alias * alias, truncated by Color's constructor
+__global__ __launch_bounds__(256) void k_average(Frame f, const uint32_t *__restrict__ sub,
+                                                 unsigned char *__restrict__ pixmap) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= f.width || y >= f.rows) return;
+    double red = 0, green = 0, blue = 0;
+    for (int q = 0; q < f.alias; q++)
+        for (int p = 0; p < f.alias; p++) {
+            const uint32_t clr = sub[xy_to_rid(x * f.alias + p, y * f.alias + q, f.tiles_x)];
+            red += (double)(int)cr(clr); green += (double)(int)cg(clr); blue += (double)(int)cb(clr);
+        }
+    const double n = (double)(f.alias * f.alias);
+    const size_t i = ((size_t)(y + f.row_begin) * (size_t)f.width + (size_t)x) * 3;
+    pixmap[i] = (unsigned char)q8(red / n); pixmap[i + 1] = (unsigned char)q8(green / n); pixmap[i + 2] = (unsigned char)q8(blue / n);
 }
 
 // Shadow rays of one group of lights for a primary hit (shader.h:395-404): the fp32 search record of
@@ -1264,16 +1306,16 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     if (rid >= f.n_rays) break;
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
-    if (!(x < f.width && y < f.rows)) {
+    if (!(x < f.grid_w && y < f.grid_h)) {
         w.rec_obj[rid] = -2;
         break;
     }
-    Ray e = calc_view(cam, (double)x / (double)f.width, (double)(y + f.row_begin) / (double)f.height);
+    Ray e = grid_ray(cam, f, x, y);
     Closest c;
     closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
         w.rec_obj[rid] = -1;
-        if (sh.n_lights == 0) store_pixel(pixmap, f, x, y, 0u);
+        if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
     // the accepted hit, in full (main.cpp:69-77)
@@ -1305,7 +1347,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_obj[rid] = obj;
     n_hit = 1;
     if (sh.n_lights == 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
-        store_pixel(pixmap, f, x, y, 0u);
+        store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
     // what every light needs of this hit: reh and the border weight do not depend on the light
@@ -1345,7 +1387,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (obj < 0) {
-        if (last) store_pixel(pixmap, f, x, y, 0u);
+        if (last) store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
     const size_t n = f.n_rays;
@@ -1376,7 +1418,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
         sum = light_mean(sum, clr, k);
     }
     if (last) {
-        store_pixel(pixmap, f, x, y, sum);
+        store_pixel(pixmap, f, w, rid, x, y, sum);
         break;
     }
     w.rec_sum[rid] = sum;
@@ -1505,6 +1547,9 @@ struct rt355_scene {
 
 extern "C" const char *rt355_last_error(void) { return g_err.c_str(); }
 extern "C" int rt355_abi_version(void) { return RT_ABI_VERSION; }
+extern "C" double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim) {
+    return rt355x_jitter(seed, x, y, sample, dim);
+}
 
 template <typename T>
 static int upload(rt355_scene *sc, const std::vector<T> &v, const T **out) {
@@ -1753,8 +1798,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
                                    const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
     if (!sc || !cam || !shader || !opts || !d_pixmap) return fail(RT355_ERR_ARG, "rt355_render_device: null argument");
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
-    if (opts->alias != 0)
-        return fail(RT355_ERR_UNSUPPORTED, "alias > 0 (jittered supersampling driven by rand(), main.cpp:286-293) is not accelerated; use alias = 0");
+    if (opts->alias < 0 || opts->alias > 64) return fail(RT355_ERR_ARG, "alias must be 0..64");
     if (shader->n_lights < 0 || (shader->n_lights && !shader->lights)) return fail(RT355_ERR_ARG, "bad light list");
     int y0 = opts->row_begin, y1 = opts->row_end;
     if (y0 == 0 && y1 == 0) y1 = opts->height;
@@ -1767,9 +1811,13 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
 
     Frame f;
     f.width = opts->width; f.height = opts->height; f.row_begin = y0; f.rows = y1 - y0;
-    f.tiles_x = (f.width + TILE_W - 1) / TILE_W; f.tiles_y = (f.rows + TILE_H - 1) / TILE_H;
-    uint64_t n_rays64 = (uint64_t)f.tiles_x * f.tiles_y * RAYS_PER_TILE;
+    f.alias = opts->alias; f.seed = opts->seed;
+    const int64_t sub = opts->alias > 0 ? opts->alias : 1;
+    const int64_t grid_w = f.width * sub, grid_h = f.rows * sub;
+    uint64_t n_rays64 = (uint64_t)((grid_w + TILE_W - 1) / TILE_W) * (uint64_t)((grid_h + TILE_H - 1) / TILE_H) * RAYS_PER_TILE;
     if (n_rays64 > 0x7fffffffull) return fail(RT355_ERR_ARG, "slab too large: split it into fewer rows per call");
+    f.grid_w = (int32_t)grid_w; f.grid_h = (int32_t)grid_h;
+    f.tiles_x = (f.grid_w + TILE_W - 1) / TILE_W; f.tiles_y = (f.grid_h + TILE_H - 1) / TILE_H;
     f.n_rays = (uint32_t)n_rays64;
     const int nl = shader->n_lights;
     const int slots = slots_for(f.n_rays, nl);
@@ -1976,12 +2024,14 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         HIP_TRY(hipEventRecord(sc->ev_resolve[3 + 2 * j], st));
         cur = next;
     }
+    if (f.alias > 0)
+        hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, st));
     sc->pending = true;
     sc->pending_stats = stats;
     sc->pending_stream = st;
-    sc->pending_primary = (uint64_t)f.width * f.rows;
+    sc->pending_primary = (uint64_t)f.grid_w * (uint64_t)f.grid_h;
     sc->pending_nprims = sc->view.n_prims;
     sc->search_launches = launches;
     sc->resolve_launches = 1 + n_groups;

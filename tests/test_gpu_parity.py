@@ -151,6 +151,31 @@ def test_frames_do_not_change_while_the_packet_size_is_tuned(api):
         assert np.array_equal(frames[0], f)
 
 
+@pytest.mark.parametrize("alias", [1, 2, 3])
+def test_supersampling_vs_checker(api, oracle, alias):
+    """alias > 0 (CalcPixel's sub-sample loop, main.cpp:289-325): jittered sub-samples from the counter-based
+    generator both sides share, averaged per pixel.  Parity is against the CPU checker, which the reference's
+    own Color arithmetic pins for this path (test_oracle_golden.py); libc's rand() stream is not reproduced."""
+    for name in ("default_2lights", "textured", "mesh", "spheres300", "spheres300_dir"):
+        sc, sh, cam, w, h = S.small_case(name)
+        w, h = (w // 2) | 1, (h // 2) | 1  # odd sizes: partial tiles of the sub-sample grid
+        cam = S.default_camera(w, h)
+        o = B.opts(w, h, alias=alias, seed=1234 + alias)
+        want, wst = oracle.render(sc.pack(), cam, sh, o, threads=0)
+        r = api.Renderer(sc)
+        for mode in (B.MODE_PACKET, B.MODE_ALLPAIRS, B.MODE_BRUTE):
+            got, st = r.render(cam, sh, w, h, alias=alias, mode=mode, seed=1234 + alias)
+            _compare(got, want)
+            assert st["primary_rays"] == wst["primary_rays"] == w * h * alias * alias
+            assert st["shadow_rays"] == wst["shadow_rays"]
+        # row slabs of a supersampled frame
+        parts = np.zeros_like(want)
+        for y0, y1 in ((0, 7), (7, h)):
+            r.render(cam, sh, w, h, alias=alias, row_begin=y0, row_end=y1, out=parts, seed=1234 + alias)
+        r.close()
+        assert np.array_equal(parts, want)
+
+
 def test_orbit_cameras_mesh(api, oracle):
     """Other view points (the camera sweep): eye bundle tables are rebuilt per frame."""
     sc = S.mesh_scene(2000, seed=3, tex_size=32)
@@ -206,7 +231,7 @@ def test_error_behaviour(api):
     sc = S.default_scene()
     r = api.Renderer(sc)
     with pytest.raises(api.Rt355Error, match="alias"):
-        r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, alias=3)
+        r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, alias=-1)
     with pytest.raises(api.Rt355Error, match="ARG"):
         r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, row_begin=40, row_end=20)
     r.close()
