@@ -1228,6 +1228,52 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
     evaluated += n;
 }
 
+// CalcShadow only uses the distance of the closest occluder (shader.h:403-415), so the shadow rays' walk
+// over the candidates keeps a minimum and nothing else.  A triangle hit at exactly t = 0 (which removes its
+// mesh, see above), an overflowed list or an unsearched bundle go through closest_hit.
+__device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
+                                                   uint32_t n_rays, const uint32_t *__restrict__ cand,
+                                                   const uint32_t *__restrict__ cand_cnt, uint32_t &evaluated,
+                                                   uint32_t &overflowed) {
+    const uint32_t n = brute ? 0u : cand_cnt[rid];
+    bool general = brute || n > CAND_CAP;
+    double bt = RT_FLT_MAX;
+    if (!general) {
+        const uint32_t *cp = cand + rid;
+        for (uint32_t k0 = 0; k0 < n; k0 += CAND_BATCH) {
+            uint32_t id[CAND_BATCH];
+            double4 rec[CAND_BATCH];
+#pragma unroll
+            for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
+#pragma unroll
+            for (int j = 0; j < CAND_BATCH; j++) rec[j] = s.prim_rec[id[j] & CAND_INDEX];
+#pragma unroll
+            for (int j = 0; j < CAND_BATCH; j++) {
+                if (k0 + j >= n) break;
+                double t;
+                if (id[j] & CAND_SPHERE) {
+                    t = sphere_t_rec(rec[j], e);
+                } else if (id[j] & CAND_TRI) {
+                    int outside; d3 ph; double u, v;
+                    t = tri_t(s.tris[__double2hiint(rec[j].x)], e, &outside, &ph, &u, &v);
+                    if (t == 0) { general = true; t = -1; }
+                } else {
+                    t = plane_t(s.objects[__double2loint(rec[j].x)], e);
+                }
+                if (t >= 0 && t < bt) bt = t;
+            }
+        }
+        evaluated += n;
+    }
+    if (general) {
+        Closest c;
+        closest_hit(s, e, brute, rid, n_rays, cand, cand_cnt, c, evaluated, overflowed);
+        if (!brute && n <= CAND_CAP) evaluated -= n; // walked twice, counted once
+        bt = c.t_best;
+    }
+    return bt;
+}
+
 // the colour of grid point (x, y): a pixel of the frame, or a sub-sample kept for k_average
 __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, const Frame &f, const Work &w,
                                             uint32_t rid, int x, int y, uint32_t clr) {
@@ -1377,6 +1423,9 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
                                                      Group next, unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_eval = 0, n_over = 0;
+#ifdef RT355_DEBUG_SURVIVORS
+    uint32_t dbg_n[LIGHT_GROUP] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const bool last = (cur.k0 + cur.count == sh.n_lights);
     bool hit = false;
     d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
@@ -1406,13 +1455,15 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
         clr = calc_specular(sh, L, clr, reh, nhl);
         if (!no_border) clr = calc_border(sh, clr, border_w);
         double shd = 0.5; // shader.h:396-398
+#ifdef RT355_DEBUG_SURVIVORS
+        dbg_n[g] = (!(dot(nh, vmul(nhl, -1)) <= 0) && cur.b[g].kind) ? w.cand_cnt[(size_t)g * n + rid] : 0u;
+#endif
         if (!(dot(nh, vmul(nhl, -1)) <= 0)) {
             Ray sr = mkview(ph, vmul(nhl, -1)); // shader.h:395,404
-            Closest c;
-            closest_hit(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
-                        w.cand_cnt + (size_t)g * n, c, n_eval, n_over);
+            const double t_min = nearest_occluder(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+                                                  w.cand_cnt + (size_t)g * n, n_eval, n_over);
             double Ld = vlen(vsub(ld3(L.position), ph)); // shader.h:412
-            shd = (c.t_best > 0 && c.t_best < Ld) ? c.t_best / Ld : 1.0;
+            shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
         }
         clr = shadow_mix(sh, L, clr, nhl, shd);
         sum = light_mean(sum, clr, k);
@@ -1428,6 +1479,14 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
         const uint32_t n_shadow = emit_shadow_rays(sh, next, w, rid, rid < f.n_rays, hit, ph, nh);
         wave_count(w.counters, 0, n_shadow);
     }
+#ifdef RT355_DEBUG_SURVIVORS
+    for (int g = 0; g < LIGHT_GROUP; g++) { // lane slots the candidate loops occupy vs candidates tested
+        uint32_t mx = dbg_n[g];
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&w.counters[12], (unsigned long long)((mx + CAND_BATCH - 1) / CAND_BATCH * CAND_BATCH) * 64ull);
+        wave_count(w.counters, 13, dbg_n[g]);
+    }
+#endif
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
 }
@@ -2090,6 +2149,8 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->packet_survivors = ctr[3];
         s->primary_hits = ctr[4];
 #ifdef RT355_DEBUG_SURVIVORS
+        { unsigned long long used = 0; for (int i = 0; i < COUNTER_SHARDS; i++) used += shards[i * COUNTER_STRIDE + 13];
+          fprintf(stderr, "[rt355] shadow candidate loops: %llu lane slots for %llu candidates (%.1f %% used)\n", shards[12], used, 100.0 * (double)used / (double)std::max(1ull, shards[12])); }
         fprintf(stderr, "[rt355] packet search: %llu waves, per wave %.2f superchunks, %.2f chunks, %.2f primitives met (max %llu)\n",
                 shards[9], (double)shards[10] / (double)std::max(1ull, shards[9]), (double)shards[11] / (double)std::max(1ull, shards[9]),
                 (double)ctr[3] / (double)std::max(1ull, shards[9]), shards[8]);

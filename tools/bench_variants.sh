@@ -8,6 +8,6 @@ for v in "$@"; do
 import json,sys
 d=json.load(open(sys.argv[2]))
 k=d["kernel_time"]
-print(f"{sys.argv[1]:10s} ms/frame {d['ms_per_step']:9.3f}  Mrays/s {d['value']:9.1f}  search ms {k['search_ms_per_frame']:8.4f}  resolve ms {k['resolve_ms_per_frame']:8.4f}")
+print(f"{sys.argv[1]:10s} ms/frame {d['ms_per_step']:9.3f}  Mrays/s {d['value']:9.1f}  search {k['search_ms_per_frame']:7.4f}  primary {k['resolve_primary_ms_per_frame']:7.4f}  shade {k['shade_ms_per_frame']:7.4f}")
 PY
 done
