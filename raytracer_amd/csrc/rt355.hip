@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
 // the shadow (shader.h:75-89), CalcShadow on the light's candidates (shader.h:393-433), the running
 // mean (shader.h:93); then either the next group's shadow rays or the pixel store (main.cpp:367-369).
 #ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 3 // waves per SIMD the shading kernel's register budget allows
+#define SHADE_MIN_WAVES 4 // waves per SIMD the shading kernel's register budget allows
 #endif
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView s, ShaderView sh, Frame f, Work w, Group cur,
                                                      Group next, unsigned char *__restrict__ pixmap) {

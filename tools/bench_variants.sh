@@ -3,7 +3,7 @@
 # usage: tools/bench_variants.sh <workload> <steps> <variant> [<variant> ...]
 wl=$1; steps=$2; shift 2; mkdir -p gpurun_out/variants
 for v in "$@"; do
-  RT355_LIB=$PWD/raytracer_amd/lib/variants/librt355_$v.so timeout -k 10 200 python bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-allpairs --workload $wl $BENCH_EXTRA > gpurun_out/variants/bench_${wl}_$v.json 2> gpurun_out/variants/bench_${wl}_$v.err || { echo "FAILED $v"; tail -3 gpurun_out/variants/bench_${wl}_$v.err; exit 1; }
+  RT355_LIB=$PWD/raytracer_amd/lib/variants/librt355_$v.so timeout -k 10 200 python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-allpairs --workload $wl $BENCH_EXTRA > gpurun_out/variants/bench_${wl}_$v.json 2> gpurun_out/variants/bench_${wl}_$v.err || { echo "FAILED $v"; tail -3 gpurun_out/variants/bench_${wl}_$v.err; exit 1; }
   python - "$v" gpurun_out/variants/bench_${wl}_$v.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[2]))
