@@ -56,6 +56,15 @@
 #define CAND_CAP 32         // candidate slots per ray; overflowing rays fall back to brute force
 // a candidate is the primitive index plus the kind of exact test it needs (the search copies the
 // kind bits from .w of the primitive's first L2 row)
+// A ray with more than CAND_CAP candidates (a ray skimming a finely tessellated surface) spills the rest as
+// (rid, id) pairs into one list per bundle; the exact tests of such a ray scan that list.  Only if the list
+// itself is full does the ray fall back to the ordered fp64 walk over every primitive.
+#define POOL_CAP (1u << 20)
+struct Spill { uint2 *pool; uint32_t *count; };
+__device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, uint32_t id) {
+    const uint32_t at = atomicAdd(sp.count, 1u);
+    if (at < POOL_CAP) sp.pool[at] = make_uint2(rid, id);
+}
 #define CAND_SPHERE 0x40000000u
 #define CAND_TRI 0x80000000u
 #define CAND_INDEX 0x3fffffffu
@@ -114,6 +123,7 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     float4 *ray32;        // [n] fp32 search record of the slot's rays (NaN = inactive)
     uint32_t *cand_cnt;   // [n] candidates found
     uint32_t *cand;       // [CAND_CAP][n]
+    Spill spill;          // [POOL_CAP] spilled candidates and [1] their count, per slot
     uint32_t *tile_count; // [tile_stride] active rays per tile, then exclusive offsets; entry [tiles] = total
     uint32_t *active_rid; // [list_stride] rids of the slot's active rays, tile-major or direction-sorted
     uint32_t *bin_hist;   // [HIST_STRIDE] packet search: rays per (direction bin, counter shard), then offsets
@@ -798,7 +808,7 @@ __device__ __forceinline__ float pair_margin(float x, float y, float z, const fl
 template <int KIND>
 __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, const float4 &c, float x, float y,
                                             float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
-                                            uint32_t &cnt) {
+                                            uint32_t &cnt, const Spill &sp) {
     float ea, eb, ec, floor_;
     if (KIND == 1) { // direction inside the pyramid over the triangle
         ea = __builtin_fmaf(z, a.z, __builtin_fmaf(y, a.y, x * a.x));
@@ -813,20 +823,23 @@ __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, co
     }
     if (fminf(ea, fminf(eb, ec)) >= floor_) {
         if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = __float_as_uint(a.w); // row 0 carries the candidate id
+        else spill_candidate(sp, rid, __float_as_uint(a.w));
         cnt++;
     }
 }
 // a primitive without rows (sphere, plane): inside the cone / circle is all there is to test
-__device__ __forceinline__ void append_id(uint32_t id, uint32_t rid, uint32_t n_rays, uint32_t *cand, uint32_t &cnt) {
+__device__ __forceinline__ void append_id(uint32_t id, uint32_t rid, uint32_t n_rays, uint32_t *cand, uint32_t &cnt,
+                                          const Spill &sp) {
     if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = id;
+    else spill_candidate(sp, rid, id);
     cnt++;
 }
 template <int KIND>
 __device__ __forceinline__ void append_candidate(const float4 *__restrict__ L2, uint32_t row, float x, float y,
                                                  float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
-                                                 uint32_t &cnt) {
+                                                 uint32_t &cnt, const Spill &sp) {
     const float4 a = L2[3 * (size_t)row], b = L2[3 * (size_t)row + 1], c = L2[3 * (size_t)row + 2];
-    append_rows<KIND>(a, b, c, x, y, z, lin, rid, n_rays, cand, cnt);
+    append_rows<KIND>(a, b, c, x, y, z, lin, rid, n_rays, cand, cnt, sp);
 }
 
 template <int KIND>
@@ -835,7 +848,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
                                                            const uint32_t *__restrict__ active_rid_all,
                                                            const uint32_t *__restrict__ n_active_all,
                                                            uint32_t *__restrict__ cand_all,
-                                                           uint32_t *__restrict__ cand_cnt_all, Slots sl,
+                                                           uint32_t *__restrict__ cand_cnt_all, Spill sp_all, Slots sl,
                                                            uint32_t list_stride, uint32_t n_active_stride) {
     // the slot of this launch row: its table, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
@@ -845,6 +858,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
+    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g;
     __shared__ float4 lds[2][PRIM_TILE];
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
@@ -899,7 +913,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
 #pragma unroll
                     for (int r = 0; r < RAYS_PER_THREAD; r++)
                         if (pair_margin<KIND>(rx[r], ry[r], rz[r], p[g]) >= (KIND == 2 ? -rz[r] : 0.0f))
-                            append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                            append_candidate<KIND>(L2, prim, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r], sp);
                 }
             }
         }
@@ -961,8 +975,8 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                                                                   const uint32_t *__restrict__ n_active_all,
                                                                   uint32_t *__restrict__ cand_all,
                                                                   uint32_t *__restrict__ cand_cnt_all,
-                                                                  unsigned long long *__restrict__ counters, Slots sl,
-                                                                  uint32_t list_stride, uint32_t n_active_stride) {
+                                                                  unsigned long long *__restrict__ counters, Spill sp_all,
+                                                                  Slots sl, uint32_t list_stride, uint32_t n_active_stride) {
     // the slot of this launch row: its tables, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
     const Tables tb = slot_tables(t_all, (size_t)sl.table[blockIdx.y]);
@@ -970,6 +984,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
+    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t total = active_rid ? *n_active : n_rays;
     if (blockIdx.x * (PACKET_THREADS * PR) >= total) return;
@@ -1124,11 +1139,11 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                         ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
 #pragma unroll
                         for (int r = 0; r < PR; r++)
-                            if (hit[r]) append_rows<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r]);
+                            if (hit[r]) append_rows<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r], sp);
                     } else {
 #pragma unroll
                         for (int r = 0; r < PR; r++)
-                            if (hit[r]) append_id(id, rid[r], n_rays, cand, cnt[r]);
+                            if (hit[r]) append_id(id, rid[r], n_rays, cand, cnt[r], sp);
                     }
                 }
             }
@@ -1159,55 +1174,65 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
 // plane hits with t >= 0 and triangle hits with t > 0, leaving out the triangles of a mesh that has a
 // hit at t = 0.  Such a mesh is only known once all candidates were seen, so if the winner belongs to it
 // the candidates are walked once more without it; two such meshes send the ray to the ordered walk over
-// everything (as does a candidate list that overflowed).
+// everything (as does a ray whose candidates did not fit its own slots AND the bundle's spill list).
 __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                             uint32_t n_rays, const uint32_t *__restrict__ cand,
-                                            const uint32_t *__restrict__ cand_cnt, Closest &c,
+                                            const uint32_t *__restrict__ cand_cnt, const Spill &sp, Closest &c,
                                             uint32_t &evaluated, uint32_t &overflowed) {
     c.init();
-    uint32_t n = 0;
+    uint32_t n = 0, n_spill = 0;
     if (!brute) {
         n = cand_cnt[rid];
-        if (n > CAND_CAP) { brute = true; overflowed += 1; }
+        if (n > CAND_CAP) { // the rest is in the bundle's spill list, unless that overflowed too
+            overflowed += 1;
+            n_spill = *sp.count;
+            if (n_spill > POOL_CAP) brute = true;
+        }
     }
     if (!brute) {
         const uint32_t *cp = cand + rid;
+        const uint32_t n_own = min(n, (uint32_t)CAND_CAP);
         int zero_obj = -1, exclude = -1;
         bool two_zero = false;
         for (int pass = 0; pass < 2; pass++) {
             double bt = RT_FLT_MAX;
             int bprim = -1, bobj = -1;
+            auto consider = [&](uint32_t id, const double4 &rec) {
+                const int prim = (int)(id & CAND_INDEX);
+                double t; int obj = -1;
+                if (id & CAND_SPHERE) {
+                    t = sphere_t_rec(rec, e);
+                } else if (id & CAND_TRI) {
+                    obj = __double2loint(rec.x);
+                    if (obj == exclude) return;
+                    int outside; d3 ph; double u, v;
+                    t = tri_t(s.tris[__double2hiint(rec.x)], e, &outside, &ph, &u, &v);
+                    if (t == 0) { // also -0.0
+                        if (zero_obj >= 0 && zero_obj != obj) two_zero = true;
+                        zero_obj = obj;
+                        return;
+                    }
+                } else {
+                    t = plane_t(s.objects[__double2loint(rec.x)], e);
+                }
+                if (t >= 0 && (t < bt || (t == bt && prim < bprim))) { bt = t; bprim = prim; bobj = obj; }
+            };
             // CAND_BATCH candidates at a time: first their ids, then their 32-byte records (independent
             // loads, all in flight together), then the tests
-            for (uint32_t k0 = 0; k0 < n; k0 += CAND_BATCH) {
+            for (uint32_t k0 = 0; k0 < n_own; k0 += CAND_BATCH) {
                 uint32_t id[CAND_BATCH];
                 double4 rec[CAND_BATCH];
 #pragma unroll
-                for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
+                for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n_own) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
 #pragma unroll
                 for (int j = 0; j < CAND_BATCH; j++) rec[j] = s.prim_rec[id[j] & CAND_INDEX];
 #pragma unroll
-                for (int j = 0; j < CAND_BATCH; j++) {
-                    if (k0 + j >= n) break;
-                    const int prim = (int)(id[j] & CAND_INDEX);
-                    double t; int obj = -1;
-                    if (id[j] & CAND_SPHERE) {
-                        t = sphere_t_rec(rec[j], e);
-                    } else if (id[j] & CAND_TRI) {
-                        obj = __double2loint(rec[j].x);
-                        if (obj == exclude) continue;
-                        int outside; d3 ph; double u, v;
-                        t = tri_t(s.tris[__double2hiint(rec[j].x)], e, &outside, &ph, &u, &v);
-                        if (t == 0) { // also -0.0
-                            if (zero_obj >= 0 && zero_obj != obj) two_zero = true;
-                            zero_obj = obj;
-                            continue;
-                        }
-                    } else {
-                        t = plane_t(s.objects[__double2loint(rec[j].x)], e);
-                    }
-                    if (t >= 0 && (t < bt || (t == bt && prim < bprim))) { bt = t; bprim = prim; bobj = obj; }
-                }
+                for (int j = 0; j < CAND_BATCH; j++)
+                    if (k0 + j < n_own) consider(id[j], rec[j]);
+            }
+            for (uint32_t i = 0; i < n_spill; i++) { // only rays with more than CAND_CAP candidates
+                const uint2 entry = sp.pool[i];
+                if (entry.x == rid) consider(entry.y, s.prim_rec[entry.y & CAND_INDEX]);
             }
             c.t_best = bt; c.prim_best = bprim;
             if (pass == 0 && zero_obj >= 0 && bobj == zero_obj && !two_zero) exclude = zero_obj; // once more without it
@@ -1231,10 +1256,21 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
 // CalcShadow only uses the distance of the closest occluder (shader.h:403-415), so the shadow rays' walk
 // over the candidates keeps a minimum and nothing else.  A triangle hit at exactly t = 0 (which removes its
 // mesh, see above), an overflowed list or an unsearched bundle go through closest_hit.
+// the rare cases of nearest_occluder (inlined: a call costs the common case more than the registers do)
+__device__ __forceinline__ double nearest_occluder_general(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
+                                                        uint32_t n_rays, const uint32_t *__restrict__ cand,
+                                                        const uint32_t *__restrict__ cand_cnt, const Spill &sp,
+                                                        uint32_t *evaluated, uint32_t *overflowed) {
+    Closest c;
+    uint32_t ev = 0, ov = 0;
+    closest_hit(s, e, brute, rid, n_rays, cand, cand_cnt, sp, c, ev, ov);
+    *evaluated += ev; *overflowed += ov;
+    return c.t_best;
+}
 __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                                    uint32_t n_rays, const uint32_t *__restrict__ cand,
-                                                   const uint32_t *__restrict__ cand_cnt, uint32_t &evaluated,
-                                                   uint32_t &overflowed) {
+                                                   const uint32_t *__restrict__ cand_cnt, const Spill &sp,
+                                                   uint32_t &evaluated, uint32_t &overflowed) {
     const uint32_t n = brute ? 0u : cand_cnt[rid];
     bool general = brute || n > CAND_CAP;
     double bt = RT_FLT_MAX;
@@ -1266,10 +1302,8 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
         evaluated += n;
     }
     if (general) {
-        Closest c;
-        closest_hit(s, e, brute, rid, n_rays, cand, cand_cnt, c, evaluated, overflowed);
+        bt = nearest_occluder_general(s, e, brute, rid, n_rays, cand, cand_cnt, sp, &evaluated, &overflowed);
         if (!brute && n <= CAND_CAP) evaluated -= n; // walked twice, counted once
-        bt = c.t_best;
     }
     return bt;
 }
@@ -1358,7 +1392,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     }
     Ray e = grid_ray(cam, f, x, y);
     Closest c;
-    closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, c, n_eval, n_over);
+    closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
         w.rec_obj[rid] = -1;
         if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u);
@@ -1460,8 +1494,9 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
 #endif
         if (!(dot(nh, vmul(nhl, -1)) <= 0)) {
             Ray sr = mkview(ph, vmul(nhl, -1)); // shader.h:395,404
+            Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_CAP; sp.count = w.spill.count + g;
             const double t_min = nearest_occluder(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
-                                                  w.cand_cnt + (size_t)g * n, n_eval, n_over);
+                                                  w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
             double Ld = vlen(vsub(ld3(L.position), ph)); // shader.h:412
             shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
         }
@@ -1739,7 +1774,7 @@ static void free_tables(rt355_scene *sc) {
 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
-    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand,
+    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
                   w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
@@ -1825,6 +1860,8 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.rec_sum, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.ray32, g * n * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, g * n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.spill.pool, g * POOL_CAP * sizeof(uint2)));
+    HIP_TRY(hipMalloc((void **)&w.spill.count, LIGHT_GROUP * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, g * CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, g * (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX) * sizeof(uint32_t)));
@@ -1958,13 +1995,15 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     // one search launch over the given slots (all of bundle kind `kind`); list / total = null for the camera rays
     auto launch_search = [&](int kind, const Slots &sl, const uint32_t *list, const uint32_t *total,
                              uint32_t total_stride) -> int {
+        for (int i = 0; i < sl.count; i++) // empty spill lists for the bundles of this launch
+            HIP_TRY(hipMemsetAsync(w.spill.count + sl.slot[i], 0, sizeof(uint32_t), st));
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
             const int cls = list ? kind : 0, pr = packet_rays_for(cls);
             sc->launch_choice.push_back({cls, pr});
             const size_t n_entries = list ? (size_t)w.list_stride : (size_t)f.n_rays, per_block = (size_t)PACKET_THREADS * pr;
             const dim3 grid((unsigned)((n_entries + per_block - 1) / per_block), (unsigned)sl.count);
-#define LAUNCH_PACKET(K, P) hipLaunchKernelGGL((k_search_packet<K, P>), grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, sl, w.list_stride, total_stride)
+#define LAUNCH_PACKET(K, P) hipLaunchKernelGGL((k_search_packet<K, P>), grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride)
             if (kind == 1 && pr == 4) LAUNCH_PACKET(1, 4);
             else if (kind == 1) LAUNCH_PACKET(1, 1);
             else if (pr == 4) LAUNCH_PACKET(2, 4);
@@ -1974,9 +2013,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             sc->launch_choice.push_back({-1, 0});
             const dim3 grid(n_tiles, (unsigned)sl.count);
             if (kind == 1)
-                hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.spill, sl, w.list_stride, total_stride);
             else
-                hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.spill, sl, w.list_stride, total_stride);
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
         launches++;

@@ -237,24 +237,34 @@ def test_error_behaviour(api):
     r.close()
 
 
-def test_candidate_overflow_falls_back_to_brute_force(api, oracle):
-    """More than 32 spheres on one line of sight: the candidate list overflows and the ray is
-    re-done over all primitives in fp64 -- the frame must still be exact."""
+def test_more_candidates_than_slots_spill(api, oracle):
+    """More than 32 primitives on one line of sight: a ray's candidate slots overflow and the rest goes through
+    the bundle's spill list -- the frame must still be exact, for spheres and for stacked mesh triangles."""
     sc = S.Scene()
     sc.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
     for i in range(48):      # nested on the view axis, all hit by the central rays
         sc.add_sphere((0.0, 5.0 + 0.75 * i, 0.0), 2.0 + 0.01 * i, (40 + 4 * i, 200 - 3 * i, 90))
     for i in range(40):      # filler so that the search path (>= 64 primitives) is taken
         sc.add_sphere((-30.0 + 1.5 * i, 60.0, 20.0), 0.5, (200, 200, 50))
-    sh = S.Shader([S.light_src(1, (0.0, -30.0, 0.5), (0, 0, -1), (1, 1, 1))], 0x101010, 0xDDDDDD, 0x000000)
+    # 45 camera-facing quads behind one another (90 front-facing triangles on the central lines of sight)
+    tris = []
+    for i in range(45):
+        y, a = 8.0 + 0.5 * i, 3.0 + 0.05 * i
+        p00, p10, p11, p01 = (-a - 12, y, -a), (a - 12, y, -a), (a - 12, y, a), (-a - 12, y, a)
+        tris.append(list(p00) + list(p10) + list(p11) + [0, 0, 1, 0, 1, 1])
+        tris.append(list(p00) + list(p11) + list(p01) + [0, 0, 1, 1, 0, 1])
+    sc.add_mesh(np.array(tris, dtype=np.float64), (90, 160, 220))
+    sh = S.Shader([S.light_src(1, (0.0, -30.0, 0.5), (0, 0, -1), (1, 1, 1)),
+                   S.light_src(0, (-100, -30, 100), (0.2, 1, -0.1), (1, 1, 1))], 0x101010, 0xDDDDDD, 0x000000)
     w, h = 96, 64
     cam = S.default_camera(w, h)
     want, _ = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
     r = api.Renderer(sc)
-    got, st = r.render(cam, sh, w, h)
+    for mode in (B.MODE_PACKET, B.MODE_ALLPAIRS):
+        got, st = r.render(cam, sh, w, h, mode=mode)
+        assert st["overflow_rays"] > 0
+        _compare(got, want)
     r.close()
-    assert st["overflow_rays"] > 0
-    _compare(got, want)
 
 
 def test_cpp_host_demo_matches_checker(api, oracle, tmp_path):
