@@ -4,9 +4,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shard frames|slabs]
                     [--mode packet|allpairs]
 
-The headline run uses the library's default search (packet: workgroup beam culling, then pair
-tests); the all-pairs search (every ray x every primitive in fp32, the FP32-VALU-bound kernel) is
-timed beside it on rank 0 at N = 1 and reported in "all_pairs" with its own roofline.
+The headline workload is the default scene at 3840x2160 (`default_4k`).  At N = 1 the two
+throughput scenes (`spheres10k_8lights_4k`, `mesh100k_2lights_4k`) are measured the same way after
+it and reported under "other_configs" of the same JSON line.  Searched scenes use the library's
+default search (packet: beams against a direction-sorted table); the all-pairs search (every ray x
+every primitive in fp32, the FP32-VALU-bound kernel) is timed beside it and reported in
+"all_pairs" with its own roofline.
 
 One step = one frame of the workload rendered by rt355_render_device into a framebuffer that
 stays in HBM (scene, tables and framebuffer are all device-resident when the timed region
@@ -126,66 +129,38 @@ def shade_bytes(stats, n_rays_padded, n_lights, w, h, searched):
     return float(n_rays_padded * 4 + hits * 88 + (stats["shadow_rays"] * 4 + cands * 4 if searched else 0) + w * h * 3)
 
 
-def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None):
-    """K frames back to back; returns per-frame averages of the HIP-event kernel times and the stats."""
-    import time as _t
+def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None, detail=False):
+    """`steps` frames back to back, each synchronised before the next is enqueued.  With detail=True the
+    HIP-event kernel times of every frame are read back and summed (not done inside timed regions)."""
     acc = {"search_ms": 0.0, "search_launches": 0, "resolve_ms": 0.0, "resolve_launches": 0, "pairs": 0,
-           "primary_ms": 0.0, "shade_ms": 0.0, "shade_launches": 0}
+           "primary_ms": 0.0, "shade_ms": 0.0, "shade_launches": 0, "frames": steps}
     stats = None
-    t0 = _t.perf_counter()
     for _ in range(steps):
         r.render_device(cam, shader, o, fb.data_ptr(), stream)
         if extra_step:
             extra_step()
-        stats = r.sync()  # waits for this frame's events (frames are serial on the stream anyway)
-        ms, n = r.search_kernel_ms()
-        acc["search_ms"] += ms; acc["search_launches"] += n
-        ms, n = r.resolve_kernel_ms()
-        acc["resolve_ms"] += ms; acc["resolve_launches"] += n
-        per = r.resolve_launch_ms()
-        acc["primary_ms"] += per[0]; acc["shade_ms"] += sum(per[1:]); acc["shade_launches"] += len(per) - 1
-        acc["pairs"] += stats["pair_tests"]
-    acc["wall_s"] = None  # filled by the caller around its own barriers
-    acc["loop_s"] = _t.perf_counter() - t0
+        stats = r.sync()
+        if detail:
+            ms, n = r.search_kernel_ms()
+            acc["search_ms"] += ms; acc["search_launches"] += n
+            ms, n = r.resolve_kernel_ms()
+            acc["resolve_ms"] += ms; acc["resolve_launches"] += n
+            per = r.resolve_launch_ms()
+            acc["primary_ms"] += per[0]; acc["shade_ms"] += sum(per[1:]); acc["shade_launches"] += len(per) - 1
+            acc["pairs"] += stats["pair_tests"]
     return acc, stats
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="spheres10k_8lights_4k")
-    ap.add_argument("--shard", choices=["frames", "slabs"], default="frames")
-    ap.add_argument("--mode", choices=["packet", "allpairs"], default="packet",
-                    help="search of the headline run: packet = workgroup beam culling before the pair tests "
-                         "(library default); allpairs = fp32 test of every ray/primitive pair")
-    ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs comparison run")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
-
+def measure(name, args, ctx, headline):
+    """One workload: W warm-up frames, K timed frames between barriers (max over ranks), then, on rank 0 and
+    outside the timed region, kernel-time breakdown, rooflines, the all-pairs comparison and the CPU baseline."""
     import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     from raytracer_amd import binding as B
     from raytracer_amd.api import Renderer
     from raytracer_amd.sharding import gather_frame, slab_rows
+    dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
 
-    scene, shader, cam, w, h = build_workload(args.workload)
+    scene, shader, cam, w, h = build_workload(name)
     r = Renderer(scene)
     fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     mode = B.MODE_PACKET if args.mode == "packet" else B.MODE_ALLPAIRS
@@ -205,75 +180,85 @@ def main():
     run_frames(r, cam, shader, o, fb, stream, args.warmup, gather)
     barrier()
     t0 = time.perf_counter()
-    acc, stats = run_frames(r, cam, shader, o, fb, stream, args.steps, gather)
+    _, stats = run_frames(r, cam, shader, o, fb, stream, args.steps, gather)
     barrier()
     dt = time.perf_counter() - t0
+    rays_step = float(stats["primary_rays"] + stats["shadow_rays"])
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        rays_local = torch.tensor([float(stats["primary_rays"] + stats["shadow_rays"])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(rays_local, op=dist.ReduceOp.SUM)
-        rays_step = float(rays_local.item())
-    else:
-        rays_step = float(stats["primary_rays"] + stats["shadow_rays"])
+        rays_all = torch.tensor([rays_step], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
+        rays_step = float(rays_all.item())
+    if rank != 0:
+        r.close()
+        return None
 
-    def valu_roofline(acc, stats, steps):
+    def valu_roofline(acc, stats):
         """FP32-VALU roofline of the all-pairs search kernel."""
         avg_ms = acc["search_ms"] / acc["search_launches"]
         pairs_per_launch = acc["pairs"] / acc["search_launches"]
         exec_tflops = pairs_per_launch * EXEC_FLOPS_PER_PAIR / (avg_ms * 1e-3) / 1e12
-        algo = algorithmic_flops(scene, shader, cam, stats) * steps / acc["search_launches"]
+        algo = algorithmic_flops(scene, shader, cam, stats) * acc["frames"] / acc["search_launches"]
         algo_tflops = algo / (avg_ms * 1e-3) / 1e12
         return {"bound": "valu_fp32", "kernel": "k_search", "achieved": round(exec_tflops, 2), "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(exec_tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                "launches_per_frame": acc["search_launches"] // steps, "avg_launch_ms": round(avg_ms, 4),
+                "launches_per_frame": acc["search_launches"] // acc["frames"], "avg_launch_ms": round(avg_ms, 4),
                 "pairs_per_launch": pairs_per_launch, "flops_per_pair_executed": EXEC_FLOPS_PER_PAIR,
                 "reference_formula_equivalent": {"tflops": round(algo_tflops, 2),
                                                  "frac_of_peak": round(algo_tflops / PEAK_FP32_TFLOPS, 4),
                                                  "flops_per_test": ALGO_FLOPS}}
 
-    if rank == 0:
-        ms_per_step = dt * 1e3 / args.steps
-        value = rays_step * args.steps / dt / 1e6
-        n_rays_padded = ((w + 31) // 32) * (((o.row_end or h) - o.row_begin + 31) // 32) * 1024
-        out = {
-            "metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": round(value, 2), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak" if (args.shard == "frames" or world == 1) else "strong",
-            "vs_baseline": None, "dtype": "f32 search + f64 resolve", "data": "synthetic",
-            "config": {"workload": args.workload, "width": w, "height": h, "primitives": scene.n_primitives,
-                       "lights": len(shader.lights), "alias": 0, "shard": args.shard, "search": args.mode,
-                       "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"]},
-                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
-                       "packet_survivors": stats["packet_survivors"]},
-        }
-        K = args.steps
-        kernels = {"search_ms_per_frame": round(acc["search_ms"] / K, 4),
-                   "resolve_primary_ms_per_frame": round(acc["primary_ms"] / K, 4),
-                   "shade_ms_per_frame": round(acc["shade_ms"] / K, 4),
-                   "resolve_ms_per_frame": round(acc["resolve_ms"] / K, 4), "frame_ms": round(ms_per_step, 4)}
-        out["kernel_time"] = kernels
-        searched = acc["search_launches"] > 0
-        nl = len(shader.lights)
+    ms_per_step = dt * 1e3 / args.steps
+    value = rays_step * args.steps / dt / 1e6
+    n_rays_padded = ((w + 31) // 32) * (((o.row_end or h) - o.row_begin + 31) // 32) * 1024
+    out = {"value": round(value, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4),
+           "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives,
+                      "lights": len(shader.lights), "alias": 0, "shard": args.shard, "search": args.mode,
+                      "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"]},
+                      "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
+                      "packet_survivors": stats["packet_survivors"]}}
+    # ---- kernel-time breakdown: a few more frames, HIP-event times read back after each
+    K = 3
+    acc, stats = run_frames(r, cam, shader, o, fb, stream, K, gather, detail=True)
+    searched = acc["search_launches"] > 0
+    nl = len(shader.lights)
+    out["kernel_time"] = {"search_ms_per_frame": round(acc["search_ms"] / K, 4),
+                          "resolve_primary_ms_per_frame": round(acc["primary_ms"] / K, 4),
+                          "shade_ms_per_frame": round(acc["shade_ms"] / K, 4), "frames_measured": K}
 
-        def hbm_roofline(kernel, bytes_frame, ms_total, launches):
-            avg_ms = ms_total / max(1, launches)
-            gbs = bytes_frame * K / max(1, launches) / (avg_ms * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_frame": launches // K,
-                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": bytes_frame}
+    def hbm_roofline(kernel, bytes_frame, ms_total, launches):
+        avg_ms = ms_total / max(1, launches)
+        gbs = bytes_frame * K / max(1, launches) / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_frame": launches // K,
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": bytes_frame}
 
-        rooflines = {
-            "k_resolve_primary": hbm_roofline("k_resolve_primary", primary_bytes(stats, n_rays_padded, nl, searched),
-                                              acc["primary_ms"], K),
-        }
+    if not searched:
+        # k_render_direct: the reference's own algorithm (every primitive tested for the camera ray and for every
+        # shadow ray, fp64), one thread per pixel.  Priced as the reference-formula flops of those tests against
+        # the FP32 vector peak; the shading of each hit (normalisations, x^25, 8-bit colour arithmetic), which
+        # the per-test figure does not count, is most of its instructions on a 4-object scene.
+        flops = algorithmic_flops(scene, shader, cam, stats)
+        avg_ms = acc["primary_ms"] / K
+        tf = flops / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_direct", "achieved": round(tf, 3),
+                           "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 5),
+                           "traffic": None, "launches_per_frame": 1, "avg_launch_ms": round(avg_ms, 4),
+                           "algorithmic_flops_per_frame": flops, "flops_per_test": ALGO_FLOPS,
+                           "algorithmic_bytes_per_frame": float(3 * w * h),
+                           "note": "arithmetic is fp64 (half the fp32 rate); per-hit shading is not in the flop count"}
+    else:
+        rooflines = {"k_resolve_primary": hbm_roofline("k_resolve_primary", primary_bytes(stats, n_rays_padded, nl, True),
+                                                       acc["primary_ms"], K)}
         if acc["shade_launches"]:
-            rooflines["k_shade_group"] = hbm_roofline("k_shade_group", shade_bytes(stats, n_rays_padded, nl, w, h, searched),
+            rooflines["k_shade_group"] = hbm_roofline("k_shade_group", shade_bytes(stats, n_rays_padded, nl, w, h, True),
                                                       acc["shade_ms"], acc["shade_launches"])
-        if searched and args.mode == "allpairs":
-            rooflines["k_search"] = valu_roofline(acc, stats, K)
-        elif searched:
+        if args.mode == "allpairs":
+            rooflines["k_search"] = valu_roofline(acc, stats)
+        else:
             # packet search: the tables stay in L2; per ray it reads the list entry (4 B, shadow rays only) and
             # the fp32 record (16 B) and writes the candidate count (4 B) and 4 B per candidate
             sb = stats["primary_rays"] * 20.0 + stats["shadow_rays"] * 24.0 + stats["exact_tests"] * 4.0
@@ -283,28 +268,82 @@ def main():
         dominant = max(rooflines, key=lambda k: times[k])
         out["roofline"] = rooflines[dominant]
         out["roofline_other_kernels"] = {k: v for k, v in rooflines.items() if k != dominant}
-        if world == 1 and args.mode == "packet" and not args.no_allpairs and acc["search_launches"]:
-            o2 = B.opts(w, h, mode=B.MODE_ALLPAIRS)
-            k2 = max(1, min(args.steps, 3))
-            run_frames(r, cam, shader, o2, fb, stream, 1)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            acc2, stats2 = run_frames(r, cam, shader, o2, fb, stream, k2)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            out["all_pairs"] = {"value": round(rays_step * k2 / dt2 / 1e6, 2), "unit": "Mrays/s", "steps": k2,
-                                "ms_per_step": round(dt2 * 1e3 / k2, 4),
-                                "search_ms_per_frame": round(acc2["search_ms"] / k2, 4),
-                                "roofline": valu_roofline(acc2, stats2, k2)}
-        if not args.no_cpu_baseline and world == 1:
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-            stride = args.cpu_stride
-            if stride == 0:
-                work = scene.n_primitives * (1 + len(shader.lights))
-                stride = 1 if work < 200 else (4 if work < 5000 else 16)
-            out["cpu_baseline"] = cpu_baseline(scene, shader, cam, w, h, stride, threads)
-        print(json.dumps(out), flush=True)
+    if world == 1 and args.mode == "packet" and not args.no_allpairs and searched:
+        o2 = B.opts(w, h, mode=B.MODE_ALLPAIRS)
+        run_frames(r, cam, shader, o2, fb, stream, 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        acc2, stats2 = run_frames(r, cam, shader, o2, fb, stream, 3, detail=True)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        out["all_pairs"] = {"value": round(rays_step * 3 / dt2 / 1e6, 2), "unit": "Mrays/s", "steps": 3,
+                            "ms_per_step": round(dt2 * 1e3 / 3, 4),
+                            "search_ms_per_frame": round(acc2["search_ms"] / 3, 4),
+                            "roofline": valu_roofline(acc2, stats2)}
+    if not args.no_cpu_baseline and world == 1:
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        stride = args.cpu_stride
+        if stride == 0:
+            work = scene.n_primitives * (1 + len(shader.lights))
+            stride = 1 if work < 200 else (4 if work < 5000 else 16)
+        out["cpu_baseline"] = cpu_baseline(scene, shader, cam, w, h, stride, threads)
     r.close()
+    return out
+
+
+HEADLINE = "default_4k"
+OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=HEADLINE)
+    ap.add_argument("--shard", choices=["frames", "slabs"], default="frames")
+    ap.add_argument("--mode", choices=["packet", "allpairs"], default="packet",
+                    help="search of searched scenes: packet = beams against a direction-sorted table "
+                         "(library default); allpairs = fp32 test of every ray/primitive pair")
+    ap.add_argument("--no-others", action="store_true", help="only the workload named, no other_configs")
+    ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs comparison run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = {"dist": dist, "world": world, "rank": rank}
+
+    head = measure(args.workload, args, ctx, headline=True)
+    others = {}
+    if world == 1 and args.workload == HEADLINE and not args.no_others:
+        for name in OTHERS:
+            others[name] = measure(name, args, ctx, headline=False)
+    if rank == 0:
+        out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak" if (args.shard == "frames" or world == 1) else "strong",
+               "vs_baseline": None, "dtype": "f64" if head["kernel_time"]["search_ms_per_frame"] == 0 else "f32 search + f64 resolve",
+               "data": "synthetic"}
+        for k in ("config", "kernel_time", "roofline", "roofline_other_kernels", "all_pairs", "cpu_baseline"):
+            if k in head:
+                out[k] = head[k]
+        if others:
+            out["other_configs"] = others
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

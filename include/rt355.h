@@ -163,7 +163,7 @@ RT355_INLINE double rt355x_jitter(uint32_t seed, int32_t x, int32_t y, int32_t s
 typedef struct rt355_stats {
     uint64_t primary_rays;   /* camera rays cast                                            */
     uint64_t shadow_rays;    /* shadow rays cast: (hit, light) pairs with N.L > 0           */
-    uint64_t pair_tests;     /* ray/primitive pairs examined by the candidate search        */
+    uint64_t pair_tests;     /* RT355_MODE_ALLPAIRS: ray/table-row pairs the search tested   */
     uint64_t exact_tests;    /* pairs evaluated by the fp64 reference formulas              */
     uint64_t overflow_rays;  /* rays whose candidate list overflowed (re-done brute force)  */
     double   ms_device;      /* HIP-event time of the device work of this call              */

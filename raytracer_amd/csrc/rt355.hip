@@ -848,8 +848,9 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
                                                            const uint32_t *__restrict__ active_rid_all,
                                                            const uint32_t *__restrict__ n_active_all,
                                                            uint32_t *__restrict__ cand_all,
-                                                           uint32_t *__restrict__ cand_cnt_all, Spill sp_all, Slots sl,
-                                                           uint32_t list_stride, uint32_t n_active_stride) {
+                                                           uint32_t *__restrict__ cand_cnt_all,
+                                                           unsigned long long *__restrict__ counters, Spill sp_all,
+                                                           Slots sl, uint32_t list_stride, uint32_t n_active_stride) {
     // the slot of this launch row: its table, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
     const Tables tb = slot_tables(t_all, (size_t)sl.table[blockIdx.y]);
@@ -879,6 +880,9 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
         if (KIND == 2) floor_lane = fminf(floor_lane, -q.z);
     }
     const int n_tiles = max(1, min(n_padded, (int)tb.hist[TB_CELLS] + PRIM_TILE - 1) / PRIM_TILE); // live rows only
+    if (t == 0) // pairs this workgroup tests: its rays x the rows it streams
+        atomicAdd(&counters[((blockIdx.x + blockIdx.y) % COUNTER_SHARDS) * COUNTER_STRIDE + 5],
+                  (unsigned long long)min((uint32_t)RAYS_PER_TILE, total - blockIdx.x * RAYS_PER_TILE) * (unsigned long long)(n_tiles * PRIM_TILE));
     float4 s0 = L1[t], s1 = L1[t + SEARCH_THREADS];
     lds[0][t] = s0; lds[0][t + SEARCH_THREADS] = s1;
     __syncthreads();
@@ -1376,6 +1380,106 @@ __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const
     return n_shadow;
 }
 
+// What Shader::shading needs of the accepted hit (main.cpp:69-77, shader.h:53-58), plus the two terms of
+// its light loop that do not depend on the light: reh of CalcSpecular and the weight of CalcBorder.
+struct HitRec {
+    d3 ph, nh, reh;
+    double border_w;
+    uint32_t cm0, cm1;
+    int obj;
+    bool no_border;
+};
+__device__ __forceinline__ HitRec primary_record(const SceneView &s, const ShaderView &sh, const Ray &e, const Closest &c) {
+    HitRec h;
+    h.obj = s.prim_obj[c.prim_best];
+    const int tri = s.prim_tri[c.prim_best];
+    const DObject &o = s.objects[h.obj];
+    double uvx = 0, uvy = 0;
+    if (tri >= 0) {
+        const DTriangle &T = s.tris[tri];
+        int outside; double u, v;
+        tri_t(T, e, &outside, &h.ph, &u, &v);
+        h.nh = vmul(ld3(T.normal), (double)outside);                 // anyobject.h:517
+        double wgt = 1 - u - v;                                      // Triangle::GetUV, anyobject.h:524-526
+        uvx = T.uv0[0] * wgt + T.uv1[0] * u + T.uv2[0] * v;
+        uvy = T.uv0[1] * wgt + T.uv1[1] * u + T.uv2[1] * v;
+    } else if (o.type == RT_OBJ_PLANE) {
+        d3 ni = ld3(o.n);
+        int outside = (dot(ni, vsub(e.pe, ld3(o.p))) <= 0) ? -1 : 1; // anyobject.h:71-77
+        h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :85
+        h.nh = vmul(ni, (double)outside);                            // :86
+    } else {
+        int outside;
+        sphere_t(o, e, &outside);
+        h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :155
+        h.nh = vmul(normalize(vsub(h.ph, ld3(o.p))), (double)outside); // :156
+    }
+    h.cm0 = o.rgb; h.cm1 = sh.ambient;
+    if (o.texture_type == 1) texture_mapping(s, o, h.ph, uvx, uvy, &h.cm0, &h.cm1); // shader.h:53-58
+    h.no_border = (o.type != RT_OBJ_SPHERE);                         // main.cpp:74
+    h.reh = mirror_dir(h.nh, e.npe);
+    h.border_w = h.no_border ? 0.0 : border_weight(e.pe, h.ph, h.nh);
+    return h;
+}
+// One turn of Shader::shading's light loop (shader.h:74-93): colour before the shadow, CalcShadow with the
+// closest occluder's distance from `occluder(shadow ray)`, running mean.
+template <class Occluder>
+__device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, const HitRec &h, uint32_t sum,
+                                                Occluder occluder, uint32_t &n_shadow) {
+    const DLight &L = sh.lights[k];
+    const d3 nhl = light_nhl(L, h.ph);
+    uint32_t clr = calc_diffuse(L, h.cm0, h.cm1, h.nh, nhl);
+    clr = calc_specular(sh, L, clr, h.reh, nhl);
+    if (!h.no_border) clr = calc_border(sh, clr, h.border_w);
+    double shd = 0.5; // shader.h:396-398
+    if (!(dot(h.nh, vmul(nhl, -1)) <= 0)) {
+        const Ray sr = mkview(h.ph, vmul(nhl, -1)); // shader.h:395,404
+        const double t_min = occluder(sr);
+        const double Ld = vlen(vsub(ld3(L.position), h.ph)); // shader.h:412
+        shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
+        n_shadow += 1;
+    }
+    clr = shadow_mix(sh, L, clr, nhl, shd);
+    return light_mean(sum, clr, k);
+}
+
+// The whole pixel in one thread, the reference's way (every primitive tested in fp64 for the camera ray and
+// for every shadow ray): used when nothing is searched -- scenes of a few objects, where tables and
+// candidate lists cost more than they save, and RT355_MODE_BRUTE.
+__global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+                                                       unsigned char *__restrict__ pixmap) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0;
+    do {
+    if (rid >= f.n_rays) break;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    if (!(x < f.grid_w && y < f.grid_h)) break;
+    const Ray e = grid_ray(cam, f, x, y);
+    Closest c;
+    Spill none; none.pool = nullptr; none.count = nullptr;
+    closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
+    uint32_t sum = 0u; // main.cpp:83: no hit -> Color(0,0,0); no lights -> clr_sum = (0,0,0), shader.h:49,95
+    if (c.prim_best >= 0) {
+        n_hit = 1;
+        if (sh.n_lights > 0) {
+            const HitRec h = primary_record(s, sh, e, c);
+            for (int k = 0; k < sh.n_lights; k++)
+                sum = shade_light(sh, k, h, sum, [&](const Ray &sr) {
+                    Closest o;
+                    closest_hit(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
+                    return o.t_best;
+                }, n_shadow);
+        }
+    }
+    store_pixel(pixmap, f, w, rid, x, y, sum);
+    } while (0);
+    wave_count(w.counters, 4, n_hit);
+    wave_count(w.counters, 0, n_shadow);
+    wave_count(w.counters, 1, n_eval);
+    wave_count(w.counters, 2, n_over);
+}
+
 __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                          int brute, Group first,
                                                          unsigned char *__restrict__ pixmap) {
@@ -1398,47 +1502,22 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
-    // the accepted hit, in full (main.cpp:69-77)
-    int obj = s.prim_obj[c.prim_best], tri = s.prim_tri[c.prim_best];
-    const DObject &o = s.objects[obj];
-    double uvx = 0, uvy = 0;
-    if (tri >= 0) {
-        const DTriangle &T = s.tris[tri];
-        int outside; double u, v;
-        tri_t(T, e, &outside, &ph, &u, &v);
-        nh = vmul(ld3(T.normal), (double)outside);                 // anyobject.h:517
-        double wgt = 1 - u - v;                                    // Triangle::GetUV, anyobject.h:524-526
-        uvx = T.uv0[0] * wgt + T.uv1[0] * u + T.uv2[0] * v;
-        uvy = T.uv0[1] * wgt + T.uv1[1] * u + T.uv2[1] * v;
-    } else if (o.type == RT_OBJ_PLANE) {
-        d3 ni = ld3(o.n);
-        int outside = (dot(ni, vsub(e.pe, ld3(o.p))) <= 0) ? -1 : 1; // anyobject.h:71-77
-        ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :85
-        nh = vmul(ni, (double)outside);                            // :86
-    } else {
-        int outside;
-        sphere_t(o, e, &outside);
-        ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :155
-        nh = vmul(normalize(vsub(ph, ld3(o.p))), (double)outside); // :156
-    }
-    uint32_t cm0 = o.rgb, cm1 = sh.ambient;
-    if (o.texture_type == 1) texture_mapping(s, o, ph, uvx, uvy, &cm0, &cm1); // shader.h:53-58
-    bool no_border = (o.type != RT_OBJ_SPHERE);                    // main.cpp:74
-    w.rec_obj[rid] = obj;
     n_hit = 1;
     if (sh.n_lights == 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
+        w.rec_obj[rid] = s.prim_obj[c.prim_best];
         store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
-    // what every light needs of this hit: reh and the border weight do not depend on the light
+    const HitRec h = primary_record(s, sh, e, c);
+    ph = h.ph; nh = h.nh;
     const size_t n = f.n_rays;
-    const d3 reh = mirror_dir(nh, e.npe);
+    w.rec_obj[rid] = h.obj;
     w.rec_d[0 * n + rid] = ph.x; w.rec_d[1 * n + rid] = ph.y; w.rec_d[2 * n + rid] = ph.z;
     w.rec_d[3 * n + rid] = nh.x; w.rec_d[4 * n + rid] = nh.y; w.rec_d[5 * n + rid] = nh.z;
-    w.rec_d[6 * n + rid] = reh.x; w.rec_d[7 * n + rid] = reh.y; w.rec_d[8 * n + rid] = reh.z;
-    if (!no_border) w.rec_d[9 * n + rid] = border_weight(e.pe, ph, nh);
-    w.rec_cm0[rid] = cm0 | (no_border ? (1u << 24) : 0u);
-    w.rec_cm1[rid] = cm1;
+    w.rec_d[6 * n + rid] = h.reh.x; w.rec_d[7 * n + rid] = h.reh.y; w.rec_d[8 * n + rid] = h.reh.z;
+    if (!h.no_border) w.rec_d[9 * n + rid] = h.border_w;
+    w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u);
+    w.rec_cm1[rid] = h.cm1;
     } while (0);
     const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, n_hit && sh.n_lights, ph, nh);
     wave_count(w.counters, 4, n_hit);
@@ -1474,34 +1553,25 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
         break;
     }
     const size_t n = f.n_rays;
-    ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
-    nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
-    const d3 reh = D3(w.rec_d[6 * n + rid], w.rec_d[7 * n + rid], w.rec_d[8 * n + rid]);
-    const uint32_t cm0w = w.rec_cm0[rid], cm0 = cm0w & 0xffffffu, cm1 = w.rec_cm1[rid];
-    const bool no_border = (cm0w >> 24) & 1u;
-    const double border_w = no_border ? 0.0 : w.rec_d[9 * n + rid];
-    uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u;
+    HitRec h;
+    h.obj = obj;
+    h.ph = ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
+    h.nh = nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+    h.reh = D3(w.rec_d[6 * n + rid], w.rec_d[7 * n + rid], w.rec_d[8 * n + rid]);
+    const uint32_t cm0w = w.rec_cm0[rid];
+    h.cm0 = cm0w & 0xffffffu; h.cm1 = w.rec_cm1[rid];
+    h.no_border = (cm0w >> 24) & 1u;
+    h.border_w = h.no_border ? 0.0 : w.rec_d[9 * n + rid];
+    uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
     for (int g = 0; g < cur.count; g++) {
-        const int k = cur.k0 + g;
-        const DLight &L = sh.lights[k];
-        const d3 nhl = light_nhl(L, ph);
-        uint32_t clr = calc_diffuse(L, cm0, cm1, nh, nhl);
-        clr = calc_specular(sh, L, clr, reh, nhl);
-        if (!no_border) clr = calc_border(sh, clr, border_w);
-        double shd = 0.5; // shader.h:396-398
-#ifdef RT355_DEBUG_SURVIVORS
-        dbg_n[g] = (!(dot(nh, vmul(nhl, -1)) <= 0) && cur.b[g].kind) ? w.cand_cnt[(size_t)g * n + rid] : 0u;
-#endif
-        if (!(dot(nh, vmul(nhl, -1)) <= 0)) {
-            Ray sr = mkview(ph, vmul(nhl, -1)); // shader.h:395,404
+        sum = shade_light(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
             Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_CAP; sp.count = w.spill.count + g;
-            const double t_min = nearest_occluder(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
-                                                  w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
-            double Ld = vlen(vsub(ld3(L.position), ph)); // shader.h:412
-            shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
-        }
-        clr = shadow_mix(sh, L, clr, nhl, shd);
-        sum = light_mean(sum, clr, k);
+#ifdef RT355_DEBUG_SURVIVORS
+            dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
+#endif
+            return nearest_occluder(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+                                    w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
+        }, unused);
     }
     if (last) {
         store_pixel(pixmap, f, w, rid, x, y, sum);
@@ -2013,9 +2083,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             sc->launch_choice.push_back({-1, 0});
             const dim3 grid(n_tiles, (unsigned)sl.count);
             if (kind == 1)
-                hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.spill, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride);
             else
-                hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.spill, sl, w.list_stride, total_stride);
+                hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride);
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
         launches++;
@@ -2093,6 +2163,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         if (any) HIP_TRY(hipMemsetAsync(w.bin_hist, 0, (size_t)gr.count * HIST_STRIDE * sizeof(uint32_t), st));
         return RT355_OK;
     };
+    if (!can_search) { // nothing to search: the whole pixel in one kernel
+        HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
+        hipLaunchKernelGGL(k_render_direct, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+        HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
+    }
     if (bundles[0].kind) {
         // camera rays: workspace slot 0, the last table slot (so that the lights' tables survive the frame)
         Slots eye{};
@@ -2108,12 +2183,14 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         if ((rc = launch_search(1, eye, nullptr, nullptr, 0))) return rc;
     }
     Group cur = group_of(0);
-    if ((rc = clear_bins(cur))) return rc;
-    HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
-    hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w,
-                       bundles[0].kind ? 0 : 1, cur, pix);
-    HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
-    for (int j = 0; j < n_groups; j++) {
+    if (can_search) {
+        if ((rc = clear_bins(cur))) return rc;
+        HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
+        hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w,
+                           bundles[0].kind ? 0 : 1, cur, pix);
+        HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
+    }
+    for (int j = 0; can_search && j < n_groups; j++) {
         if ((rc = search_group(cur))) return rc;
         Group next = group_of(j + 1);
         if ((rc = clear_bins(next))) return rc;
@@ -2132,7 +2209,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     sc->pending_primary = (uint64_t)f.grid_w * (uint64_t)f.grid_h;
     sc->pending_nprims = sc->view.n_prims;
     sc->search_launches = launches;
-    sc->resolve_launches = 1 + n_groups;
+    sc->resolve_launches = can_search ? 1 + n_groups : 1;
     return RT355_OK;
 }
 
@@ -2142,10 +2219,10 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     HIP_TRY(hipSetDevice(sc->device));
     HIP_TRY(hipEventSynchronize(sc->ev_end));
     sc->pending = false;
-    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[5] = {0, 0, 0, 0, 0};
+    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(shards, sc->work.counters, sizeof shards, hipMemcpyDeviceToHost));
     for (int i = 0; i < COUNTER_SHARDS; i++)
-        for (int j = 0; j < 5; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
+        for (int j = 0; j < 6; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
     sc->search_ms = 0;
@@ -2183,7 +2260,7 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->shadow_rays = ctr[0];
         s->exact_tests = ctr[1];
         s->overflow_rays = ctr[2];
-        s->pair_tests = (sc->pending_primary + ctr[0]) * (uint64_t)sc->pending_nprims;
+        s->pair_tests = ctr[5];
         s->ms_device = ms;
         s->packet_survivors = ctr[3];
         s->primary_hits = ctr[4];
