@@ -1,17 +1,23 @@
 // rt355.hip -- kernels and C ABI of the MI355X renderer (gfx950 only).
 //
-// Frame pipeline (all on one HIP stream):
+// Frame pipeline (all on one HIP stream; kernels that serve several lights take the light's slot
+// from blockIdx.y):
+//   scenes of a few objects, and mode BRUTE:
+//   k_render_direct   the whole pixel in one thread, every primitive tested in fp64
+//   everything else:
 //   k_gen_primary     camera rays (CalcView, main.cpp:269-276) -> fp32 directions
-//   k_bundle_origin / k_bundle_direction   per (ray bundle, primitive): fp32 bounding cone or
-//                     circle + edge tables
-//   k_search_packet / k_search   THE SEARCH: rays of a bundle against the primitive table, fp32,
-//                     conservative (no false negatives) -> per-ray candidate lists
+//   k_table_*         per bundle: fp32 bounding cones / circles and edge rows of the primitives, sorted by
+//                     direction as seen from the bundle, chunk and superchunk bounds (kept while the
+//                     bundle does not change)
+//   k_search_packet / k_search   THE SEARCH: rays of a bundle against the table, fp32, conservative
+//                     (no false negatives) -> per-ray candidate lists
 //   k_resolve_primary fp64 reference formulas on the candidates -> closest hit, texture lookup,
 //                     hit record, and the shadow rays of the first group of lights
-//   (per light of the group: bundle table, direction sort, search -- one workspace slot each)
+//   k_scan_bins, k_bin_scatter   counting sort of each light's shadow rays by direction
 //   k_shade_group     per hit and light of the group: fp64 closest occluder on the candidates,
 //                     diffuse / specular / border / CalcShadow, running mean; then the next
 //                     group's shadow rays or the final RGB8 store
+//   k_average         alias > 0: mean of a pixel's sub-samples
 //
 // A "bundle" is a set of rays with a common origin: the camera rays (origin = eye) or the
 // shadow rays of one point/spot/area light traced backwards (origin = light position).  For
