@@ -185,10 +185,10 @@ def measure(name, args, ctx, headline):
     dt = time.perf_counter() - t0
     rays_step = float(stats["primary_rays"] + stats["shadow_rays"])
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        rays_all = torch.tensor([rays_step], dtype=torch.float64, device="cuda")
+        rays_all = torch.tensor([rays_step], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
         rays_step = float(rays_all.item())
     if rank != 0:
@@ -321,11 +321,19 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    # rehearsal of the N > 1 path on a one-GPU box: every rank on device 0, collectives over gloo (RCCL refuses
+    # two ranks on one device)
+    share = bool(os.environ.get("RT355_BENCH_SHARE_GPU"))
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = {"dist": dist, "world": world, "rank": rank}
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = {"dist": dist, "world": world, "rank": rank, "reduce_device": "cpu" if share else "cuda"}
 
     head = measure(args.workload, args, ctx, headline=True)
     others = {}
