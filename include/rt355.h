@@ -48,7 +48,7 @@ typedef struct rt355_object {
                          n1 = n0 x ni as the Plane ctor does (:57); this field is ignored. */
     double n2[3];     /* Sphere::n2 (:105)                                                   */
     double radius;    /* Sphere::radius (:102)                                               */
-    double ks;        /* AnyObject::ks (:22); must be 0 (no reflection recursion yet)        */
+    double ks;        /* AnyObject::ks (:22); != 0 is rendered only without a search (see rt355_render) */
     double fresnel;   /* AnyObject::fresnel (:21); must be 1 (no refraction yet)             */
     double ior;       /* AnyObject::IOR (:20); carried, unused while fresnel == 1            */
     int32_t type;     /* RT355_OBJ_*                                                         */
@@ -169,6 +169,7 @@ typedef struct rt355_stats {
     double   ms_device;      /* HIP-event time of the device work of this call              */
     uint64_t packet_survivors; /* RT355_MODE_PACKET: (wave, primitive) pairs that passed both beam tests */
     uint64_t primary_hits;   /* camera rays that hit something                              */
+    uint64_t secondary_rays; /* reflection rays cast (main.cpp:97-108)                      */
 } rt355_stats;
 
 typedef struct rt355_scene rt355_scene; /* opaque, library-owned, bound to one HIP device */

@@ -143,11 +143,14 @@ View calc_view(const Cam &k, double x_per, double y_per) {
     return View(k.p_eye, npe);
 }
 
-// CalcSubPixel's closest-hit loop and shading call (main.cpp:65-91), re-expressed.  The
-// recursion at main.cpp:93-155 is inert for ks == 0, fresnel == 1.
-Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd) {
+// CalcSubPixel for outside = 1 and fresnel == 1 objects, re-expressed line by line with the reference's
+// classes: closest-hit loop and shading call (main.cpp:65-91), reflection recursion (main.cpp:93-112,
+// thresholds main.cpp:27-28).  The refraction branch (main.cpp:116-154) is not reached with fresnel == 1.
+Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd, int reflection_times = 0,
+                double reflection_ktotal = 1.0) {
     double t_min = FLT_MAX;
     int object_index = 0;
+    Color clr = Color(0, 0, 0);
     Color cm0(0, 0, 0);
     Point3D ph(0, 0, 0);
     Vector3D nh(0, 0, 0);
@@ -165,8 +168,20 @@ Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd) {
         }
     }
     if (t_min != FLT_MAX)
-        return shd.shading(cm0, shd.ambient_color, ph, nh, eye, no_border, objs, object_index, UV, 0, 0);
-    return Color(0, 0, 0);
+        clr = shd.shading(cm0, shd.ambient_color, ph, nh, eye, no_border, objs, object_index, UV, 0, 0);
+    if (objs.empty()) return clr;
+    double ks = objs[object_index]->ks;
+    reflection_ktotal *= ks;
+    reflection_times++;
+    Color clr_reflection;
+    if (reflection_times <= 3 && reflection_ktotal >= 0.05) {
+        Vector3D reflect_npe = eye.npe - nh * 2 * DotProduct(nh, eye.npe);
+        View reflect_view = View(ph, reflect_npe);
+        clr_reflection = clr * (1 - ks) + sub_pixel(reflect_view, objs, shd, reflection_times, reflection_ktotal) * ks;
+    } else {
+        clr_reflection = clr;
+    }
+    return clr_reflection;
 }
 
 std::vector<light_src *> make_lights(const rt355_shader *sh) {

@@ -259,6 +259,7 @@ typedef struct {
     const oscene *s;
     const rt355_shader *sh;
     uint64_t shadow_rays;
+    uint64_t secondary_rays;
 } octx;
 
 static col calc_diffuse(const rt355_light *L, col cm0, col cm1, v3 nh, v3 nhl) { /* shader.h:324-338 */
@@ -326,13 +327,16 @@ static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_bor
     return clr_sum;
 }
 
-/* CalcSubPixel, main.cpp:42-91 with reflection_times=0, outside=1; the recursion at
- * :93-155 is inert because every object has ks == 0 and fresnel == 1. */
-static col calc_subpixel(octx *cx, ray eye) {
+/* CalcSubPixel, main.cpp:42-158, for outside = 1 and objects with fresnel == 1: closest hit and shading
+ * (:65-91), then the reflection recursion (:93-112) with REFLECTION_TIMES_THRES 3 and
+ * REFLECTION_KTOTAL_THRES 0.05 (:27-28).  On a miss object_index stays 0, ph and nh stay zero, and the
+ * reference goes on with objs[0]'s ks (:94); so does this.  Refraction (:116-154) needs fresnel < 1. */
+static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double reflection_ktotal) {
     int n = cx->s->d->n_objects;
     double t_min = FLT_MAX;
     hit best; memset(&best, 0, sizeof best);
     int idx = 0, no_border = 1;
+    col clr = C(0, 0, 0);
     for (int i = 0; i < n; i++) {
         hit h = obj_isect(cx->s, i, eye);
         if (h.t >= 0 && h.t < t_min) {
@@ -343,12 +347,24 @@ static col calc_subpixel(octx *cx, ray eye) {
     if (t_min != FLT_MAX) {
         const rt355_object *o = &cx->s->d->objects[idx];
         const rt355_shader *sh = cx->sh;
-        return shading(cx, C(o->rgb[0], o->rgb[1], o->rgb[2]),
-                       C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), best.ph, best.nh, eye,
-                       no_border, idx, best.uvx, best.uvy);
+        clr = shading(cx, C(o->rgb[0], o->rgb[1], o->rgb[2]),
+                      C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), best.ph, best.nh, eye,
+                      no_border, idx, best.uvx, best.uvy);
     }
-    return C(0, 0, 0);
+    if (n == 0) return clr; /* the reference would read objs[0] of an empty vector here */
+    double ks = cx->s->d->objects[idx].ks;                                     /* :94 */
+    reflection_ktotal *= ks;                                                   /* :97 */
+    reflection_times++;                                                        /* :98-100, outside >= 1 */
+    if (reflection_times <= 3 && reflection_ktotal >= 0.05) {                  /* :103 */
+        v3 reflect_npe = vsub(eye.npe, vmul(vmul(best.nh, 2), dot(best.nh, eye.npe))); /* :104 */
+        ray reflect_view = mkview(best.ph, reflect_npe);                      /* :108 */
+        cx->secondary_rays++;
+        col sub = calc_subpixel_rec(cx, reflect_view, reflection_times, reflection_ktotal);
+        return cadd(cmul(clr, 1 - ks), cmul(sub, ks));                         /* :109 */
+    }
+    return clr;                                                                /* :111, :151 */
 }
+static col calc_subpixel(octx *cx, ray eye) { return calc_subpixel_rec(cx, eye, 0, 1.0); }
 
 typedef struct { v3 p_eye, n0, n1, p00; double s_x, s_y; } ocam;
 /* Scene::SetCamera, main.cpp:255-262 */
@@ -404,15 +420,15 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
     int y0 = opts->row_begin, y1 = opts->row_end;
     if (y0 == 0 && y1 == 0) y1 = H;
     if (stride < 1) stride = 1;
-    uint64_t prim = 0, shad = 0;
+    uint64_t prim = 0, shad = 0, sec = 0;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
     (void)n_threads;
-#pragma omp parallel for schedule(static, 1) reduction(+ : prim, shad)
+#pragma omp parallel for schedule(static, 1) reduction(+ : prim, shad, sec)
     for (int y = y0; y < y1; y++) {
         if (y % stride) continue;
-        octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0;
+        octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0; cx.secondary_rays = 0;
         const int alias = opts->alias;
         for (int x = 0; x < W; x += stride) {
             col clr;
@@ -438,12 +454,14 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
             pixmap[i] = clr.r; pixmap[i + 1] = clr.g; pixmap[i + 2] = clr.b;
         }
         shad += cx.shadow_rays;
+        sec += cx.secondary_rays;
     }
     free(s.tris);
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->primary_rays = prim;
         stats->shadow_rays = shad;
+        stats->secondary_rays = sec;
     }
     return RT355_OK;
 }

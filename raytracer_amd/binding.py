@@ -71,14 +71,15 @@ class COpts(C.Structure):
 class CStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("pair_tests", C.c_uint64), ("exact_tests", C.c_uint64),
-                ("overflow_rays", C.c_uint64), ("ms_device", C.c_double), ("packet_survivors", C.c_uint64), ("primary_hits", C.c_uint64)]
+                ("overflow_rays", C.c_uint64), ("ms_device", C.c_double), ("packet_survivors", C.c_uint64), ("primary_hits", C.c_uint64),
+                ("secondary_rays", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 assert C.sizeof(CTexture) == 32 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
-assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 32 and C.sizeof(CStats) == 64
+assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 32 and C.sizeof(CStats) == 72
 
 
 def _normalize(v: Sequence[float]):

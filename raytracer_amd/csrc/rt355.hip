@@ -1452,24 +1452,42 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
 // The whole pixel in one thread, the reference's way (every primitive tested in fp64 for the camera ray and
 // for every shadow ray): used when nothing is searched -- scenes of a few objects, where tables and
 // candidate lists cost more than they save, and RT355_MODE_BRUTE.
+// REFLECT: the reflection recursion of CalcSubPixel (main.cpp:93-112) as a loop over at most four rays per
+// pixel (REFLECTION_TIMES_THRES 3, REFLECTION_KTOTAL_THRES 0.05, main.cpp:27-28), colours folded back from the
+// deepest.  On a miss the reference goes on with objs[0]'s ks, a zero hit point and a zero normal; so does
+// this.  Compiled apart so that scenes without mirrors do not carry the loop.
+template <bool REFLECT>
 __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                        unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0;
+    uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0;
     do {
     if (rid >= f.n_rays) break;
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (!(x < f.grid_w && y < f.grid_h)) break;
-    const Ray e = grid_ray(cam, f, x, y);
-    Closest c;
+    Ray e = grid_ray(cam, f, x, y);
     Spill none; none.pool = nullptr; none.count = nullptr;
-    closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
-    uint32_t sum = 0u; // main.cpp:83: no hit -> Color(0,0,0); no lights -> clr_sum = (0,0,0), shader.h:49,95
-    if (c.prim_best >= 0) {
-        n_hit = 1;
-        if (sh.n_lights > 0) {
+    constexpr int LEVELS = REFLECT ? 4 : 1;
+    uint32_t level_clr[LEVELS];
+    double level_ks[LEVELS];
+    int deepest = 0;
+    double ktotal = 1.0;
+    bool alive = true;
+#pragma unroll
+    for (int level = 0; level < LEVELS; level++) {
+        level_clr[level] = 0u; level_ks[level] = 0.0;
+        if (!alive) continue;
+        deepest = level;
+        Closest c;
+        closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
+        uint32_t sum = 0u; // main.cpp:83: no hit -> Color(0,0,0); no lights -> clr_sum = (0,0,0), shader.h:49,95
+        d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
+        int obj = 0;
+        if (c.prim_best >= 0) {
+            if (level == 0) n_hit = 1;
             const HitRec h = primary_record(s, sh, e, c);
+            ph = h.ph; nh = h.nh; obj = h.obj;
             for (int k = 0; k < sh.n_lights; k++)
                 sum = shade_light(sh, k, h, sum, [&](const Ray &sr) {
                     Closest o;
@@ -1477,13 +1495,31 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
                     return o.t_best;
                 }, n_shadow);
         }
+        level_clr[level] = sum;
+        if (REFLECT) {
+            const double ks = s.n_objects > 0 ? s.objects[obj].ks : 0.0;      // main.cpp:94
+            level_ks[level] = ks;
+            ktotal *= ks;                                                      // :97
+            alive = (level + 1 <= 3) && (ktotal >= 0.05) && s.n_objects > 0;   // :98-103: reflection_times = level + 1
+            if (alive && level + 1 < LEVELS) {
+                e = mkview(ph, vsub(e.npe, vmul(vmul(nh, 2), dot(nh, e.npe)))); // :104-108
+                n_secondary += 1;
+            }
+        }
     }
-    store_pixel(pixmap, f, w, rid, x, y, sum);
+    uint32_t clr = 0u; // clr * (1 - ks) + CalcSubPixel(reflected ray) * ks, from the deepest ray back (main.cpp:109)
+#pragma unroll
+    for (int level = LEVELS - 1; level >= 0; level--) {
+        if (level == deepest) clr = level_clr[level];
+        else if (level < deepest) clr = cadd(cmul(level_clr[level], 1 - level_ks[level]), cmul(clr, level_ks[level]));
+    }
+    store_pixel(pixmap, f, w, rid, x, y, clr);
     } while (0);
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
+    if (REFLECT) wave_count(w.counters, 6, n_secondary);
 }
 
 __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
@@ -1681,6 +1717,7 @@ struct rt355_scene {
     SceneView view{};
     int n_padded = 0;
     bool has_tris = false;
+    bool reflective = false; // some object has ks != 0
     double rmax = 0;   // largest sphere radius / triangle bounding radius
     double extent = 0; // largest |coordinate| of a sphere centre or triangle vertex
     // owned device allocations of the scene
@@ -1741,13 +1778,15 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     std::vector<DTriangle> tris(d->n_triangles);
     std::vector<int32_t> prim_obj, prim_tri;
     std::vector<double4> prim_rec;
+    bool any_ks = false;
     double rmax = 0, extent = 0;
     for (int i = 0; i < d->n_objects; i++) {
         const rt355_object &o = d->objects[i];
         if (o.type != RT355_OBJ_PLANE && o.type != RT355_OBJ_SPHERE && o.type != RT355_OBJ_MESH)
             return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": only Plane, Sphere and Mesh are accelerated");
-        if (o.ks != 0 || o.fresnel != 1)
-            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": ks != 0 or fresnel != 1 (reflection/refraction recursion, main.cpp:93-155, is not accelerated)");
+        if (o.fresnel != 1)
+            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": fresnel != 1 (refraction, main.cpp:116-154, is not accelerated)");
+        if (o.ks != 0) any_ks = true;
         if (o.texture_type != 0 && o.texture_type != 1)
             return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": texture_type 2/3 (solid / procedural) is not accelerated");
         if (o.texture_type == 1 && (o.tex0 < 0 || o.tex1 < 0 || o.tex0 >= d->n_textures || o.tex1 >= d->n_textures))
@@ -1758,6 +1797,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         memcpy(q.n0, o.n0, sizeof q.n0); memcpy(q.n1, o.n1, sizeof q.n1); memcpy(q.n2, o.n2, sizeof q.n2);
         if (o.type == RT355_OBJ_PLANE) put3(q.n1, hcross(H3(o.n0), H3(o.n))); // Plane ctor, anyobject.h:57
         q.radius = o.radius;
+        q.ks = o.ks;
         q.type = o.type; q.texture_type = o.texture_type; q.tex0 = o.tex0; q.tex1 = o.tex1;
         q.tri_begin = o.tri_begin; q.tri_count = o.tri_count;
         q.rgb = pack_rgb(o.rgb);
@@ -1826,6 +1866,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->tables.top_stride = (sc->n_table / 4096 + 63) / 64 * 64;
     sc->tables.n_prims_pad = std::max(256, (sc->view.n_prims + 255) / 256 * 256);
     sc->has_tris = d->n_triangles > 0;
+    sc->reflective = any_ks;
     sc->rmax = rmax; sc->extent = extent;
     HIP_TRY(hipEventCreate(&sc->ev_begin));
     HIP_TRY(hipEventCreate(&sc->ev_end));
@@ -2021,6 +2062,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     // bundle 0 = camera rays (common origin: the eye); bundle 1+k = shadow rays of light k (common
     // origin: the light position, or common direction for a directional light)
     const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
+    if (can_search && sc->reflective)
+        return fail(RT355_ERR_UNSUPPORTED, "objects with ks != 0 (reflection rays, main.cpp:93-112) are rendered only without a search so far: "
+                                           "scenes of fewer than 64 primitives, or RT355_MODE_BRUTE");
     std::vector<Bundle> bundles(2 + nl);
     for (auto &b : bundles) memset(&b, 0, sizeof b);
     if (can_search) {
@@ -2171,7 +2215,10 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     };
     if (!can_search) { // nothing to search: the whole pixel in one kernel
         HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
-        hipLaunchKernelGGL(k_render_direct, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+        if (sc->reflective)
+            hipLaunchKernelGGL(k_render_direct<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+        else
+            hipLaunchKernelGGL(k_render_direct<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
     }
     if (bundles[0].kind) {
@@ -2225,10 +2272,10 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     HIP_TRY(hipSetDevice(sc->device));
     HIP_TRY(hipEventSynchronize(sc->ev_end));
     sc->pending = false;
-    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[7] = {0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(shards, sc->work.counters, sizeof shards, hipMemcpyDeviceToHost));
     for (int i = 0; i < COUNTER_SHARDS; i++)
-        for (int j = 0; j < 6; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
+        for (int j = 0; j < 7; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
     sc->search_ms = 0;
@@ -2270,6 +2317,7 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->ms_device = ms;
         s->packet_survivors = ctr[3];
         s->primary_hits = ctr[4];
+        s->secondary_rays = ctr[6];
 #ifdef RT355_DEBUG_SURVIVORS
         { unsigned long long used = 0; for (int i = 0; i < COUNTER_SHARDS; i++) used += shards[i * COUNTER_STRIDE + 13];
           fprintf(stderr, "[rt355] shadow candidate loops: %llu lane slots for %llu candidates (%.1f %% used)\n", shards[12], used, 100.0 * (double)used / (double)std::max(1ull, shards[12])); }

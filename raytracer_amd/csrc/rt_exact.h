@@ -72,6 +72,7 @@ struct DObject { // one entry of Scene::objs, as uploaded
     int32_t type, texture_type, tex0, tex1, tri_begin, tri_count;
     uint32_t rgb; // 0x00BBGGRR
     int32_t pad_;
+    double ks;    // reflection coefficient (anyobject.h:22)
 };
 struct DTriangle { // Triangle with its ctor-derived members (anyobject.h:456-461)
     double p0[3], p1[3], p2[3];

@@ -268,8 +268,23 @@ def small_case(name: str):
         sh = Shader([light_src(1, (30, -30, 50), (0, 0, -1), (1, 1, 1)),
                      light_src(1, (2, -12, 6), (0, 0, -1), (1, 1, 1))], 0x0A0A0A, 0xDDDDDD, 0x000000)
         return s, sh, default_camera(w, h), w, h
+    if name == "mirrors":
+        # the default scene with reflecting objects (ks of anyobject.h:22): a faint floor, a mirror wall, one
+        # glossy and one almost perfect mirror sphere; object 0 reflects, so rays that miss go on (main.cpp:94)
+        w, h = 160, 120
+        s = default_scene()
+        for o, ks in zip(s.objects, (0.25, 0.5, 0.6, 0.95)):
+            o["ks"] = ks
+        return s, default_shader(2), default_camera(w, h), w, h
+    if name == "mirrors_mesh":
+        # a reflecting textured mesh over a matt floor, two mirror spheres, three lights incl. a directional one
+        w, h = 128, 96
+        s, sh, cam, _, _ = small_case("mesh_dir")
+        for o, ks in zip(s.objects, (0.0, 0.35, 0.8, 0.5, 0.5, 0.5)):
+            o["ks"] = ks
+        return s, sh, default_camera(w, h), w, h
     raise KeyError(name)
 
 
 SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
-               "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside"]
+               "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside", "mirrors", "mirrors_mesh"]

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     from raytracer_amd import binding as B
     assert B.OBJECT_DTYPE.itemsize == 184 and B.LIGHT_DTYPE.itemsize == 80
-    assert ctypes.sizeof(B.CCamera) == 96 and ctypes.sizeof(B.CStats) == 64
+    assert ctypes.sizeof(B.CCamera) == 96 and ctypes.sizeof(B.CStats) == 72
 
 
 def test_null_arguments_are_rejected_without_a_gpu():

@@ -45,22 +45,44 @@ def test_small_cases_vs_golden(api, golden_dir, name, mode):
     gold = np.load(os.path.join(golden_dir, f"frame_{name}.npy"))
     sc, sh, cam, w, h = S.small_case(name)
     r = api.Renderer(sc)
+    if mode != B.MODE_BRUTE and sc.n_primitives >= 64 and any(float(o["ks"]) != 0 for o in sc.objects):
+        # reflection rays have no search yet: refused, with the way out named
+        with pytest.raises(api.Rt355Error, match="RT355_MODE_BRUTE"):
+            r.render(cam, sh, w, h, mode=mode)
+        r.close()
+        return
     frame, st = r.render(cam, sh, w, h, mode=mode)
     r.close()
     _compare(frame, gold, exact=(name != "textured"))
     assert st["primary_rays"] == w * h
 
 
-@pytest.mark.parametrize("name", ["mesh", "spheres300", "inside", "default_2lights"])
+@pytest.mark.parametrize("name", ["mesh", "spheres300", "inside", "default_2lights", "mirrors", "mirrors_mesh"])
 def test_ray_counts_match_checker(api, oracle, name):
     sc, sh, cam, w, h = S.small_case(name)
     _, want = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=4)
     r = api.Renderer(sc)
-    _, st = r.render(cam, sh, w, h)
+    _, st = r.render(cam, sh, w, h, mode=B.MODE_BRUTE if name.startswith("mirrors") else B.MODE_PACKET)
     r.close()
     assert st["primary_rays"] == want["primary_rays"]
     assert st["shadow_rays"] == want["shadow_rays"]
+    assert st["secondary_rays"] == want["secondary_rays"]
+    assert (st["secondary_rays"] > 0) == name.startswith("mirrors")
     assert st["overflow_rays"] == 0
+
+
+def test_mirrors_supersampled(api, oracle):
+    """Reflection rays under alias > 0: every sub-sample runs its own chain of up to three reflections."""
+    sc, sh, cam, w, h = S.small_case("mirrors")
+    w, h = 81, 61
+    cam = S.default_camera(w, h)
+    o = B.opts(w, h, alias=2, seed=77)
+    want, wst = oracle.render(sc.pack(), cam, sh, o, threads=0)
+    r = api.Renderer(sc)
+    got, st = r.render(cam, sh, w, h, alias=2, seed=77)
+    r.close()
+    _compare(got, want)
+    assert st["secondary_rays"] == wst["secondary_rays"] > 0
 
 
 def test_probe_intersections_bit_exact(api, golden_dir):
@@ -225,7 +247,7 @@ def test_full_size_properties(api, oracle):
 
 def test_error_behaviour(api):
     sc = S.default_scene()
-    sc.objects[2]["ks"] = 0.5
+    sc.objects[2]["fresnel"] = 0.5
     with pytest.raises(api.Rt355Error, match="UNSUPPORTED"):
         api.Renderer(sc)
     sc = S.default_scene()
