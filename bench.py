@@ -92,9 +92,10 @@ def algorithmic_flops(scene, shader, cam, stats) -> float:
 
 
 def cpu_baseline(scene, shader, cam, w, h, stride, threads):
-    """The CPU checker (oracle/rt_oracle.c, a port of the reference path) timed on a strided
-    pixel sample of the same frame."""
-    from oracle.oracle_py import Oracle
+    """The CPU checker (oracle/rt_oracle.c, a port of the reference path) timed on a strided pixel sample of
+    the same frame, all `threads` cores and one; and, where the harness around the reference's own classes was
+    built (oracle/_ref), that code on a few rows of the same frame, one thread as the reference runs."""
+    from oracle.oracle_py import Oracle, Reference
     from raytracer_amd import binding as B
     O = Oracle()
     p = scene.pack()
@@ -102,9 +103,32 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads):
     _, st = O.render(p, cam, shader, B.opts(w, h), threads=threads, stride=stride)
     dt = time.perf_counter() - t0
     rays = st["primary_rays"] + st["shadow_rays"]
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
-                      f"{st['shadow_rays']} shadow rays, {dt:.2f} s)"}
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
+                     f"{st['shadow_rays']} shadow rays, {dt:.2f} s)"}
+    # one thread of the same port, on a sample a thread finishes in seconds
+    s1 = stride * (4 if scene.n_primitives >= 1000 else 1)
+    t0 = time.perf_counter()
+    _, st1 = O.render(p, cam, shader, B.opts(w, h), threads=1, stride=s1)
+    dt1 = time.perf_counter() - t0
+    out["one_thread"] = {"value": (st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6, "unit": "Mrays/s",
+                         "sample": f"every {s1}th pixel in x and y ({dt1:.2f} s)"}
+    # the reference's own classes (CalcIntersect, Shader::shading, Color ...) driven by the harness, one thread
+    work = scene.n_primitives * (1 + len(shader.lights))
+    rows = 64 if work < 200 else (1 if work < 200_000 else 0)
+    if Reference.available() and rows:
+        R = Reference()
+        o = B.opts(w, h, row_begin=h // 2, row_end=h // 2 + rows)
+        _, sts = O.render(p, cam, shader, o, threads=threads)  # the slab's ray counts
+        t0 = time.perf_counter()
+        R.render(p, cam, shader, o)
+        dtr = time.perf_counter() - t0
+        out["reference_classes_one_thread"] = {
+            "value": (sts["primary_rays"] + sts["shadow_rays"]) / dtr / 1e6, "unit": "Mrays/s", "kind": "reference",
+            "sample": f"rows {h // 2}..{h // 2 + rows - 1} of the same frame ({sts['primary_rays']} primary + "
+                      f"{sts['shadow_rays']} shadow rays, {dtr:.2f} s); the harness compiles the reference's headers, "
+                      f"main.cpp itself needs GLUT"}
+    return out
 
 
 def primary_bytes(stats, n_rays_padded, n_lights, searched):

@@ -425,9 +425,11 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
     (void)n_threads;
-#pragma omp parallel for schedule(static, 1) reduction(+ : prim, shad, sec)
-    for (int y = y0; y < y1; y++) {
-        if (y % stride) continue;
+    const int y_first = (y0 + stride - 1) / stride * stride; /* sampled rows: multiples of stride; dealt out one by one */
+    const int n_sampled = y_first < y1 ? (y1 - y_first + stride - 1) / stride : 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : prim, shad, sec)
+    for (int j = 0; j < n_sampled; j++) {
+        const int y = y_first + j * stride;
         octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0; cx.secondary_rays = 0;
         const int alias = opts->alias;
         for (int x = 0; x < W; x += stride) {
