@@ -5,8 +5,9 @@
                     [--mode packet|allpairs]
 
 The headline workload is the default scene at 3840x2160 (`default_4k`).  At N = 1 the two
-throughput scenes (`spheres10k_8lights_4k`, `mesh100k_2lights_4k`) are measured the same way after
-it and reported under "other_configs" of the same JSON line.  Searched scenes use the library's
+throughput scenes (`spheres10k_8lights_4k`, `mesh100k_2lights_4k`) and the default scene under the
+renderer HEAD of the reference selects (`default_bleed162_4k`: CalcSubPixel2 with shading3 on 162 gather
+directions) are measured the same way after it and reported under "other_configs" of the same JSON line.  Searched scenes use the library's
 default search (packet: beams against a direction-sorted table); the all-pairs search (every ray x
 every primitive in fp32, the FP32-VALU-bound kernel) is timed beside it and reported in
 "all_pairs" with its own roofline.
@@ -47,7 +48,7 @@ def build_workload(name: str):
     if name == "spheres10k_8lights_4k":
         w, h = 3840, 2160
         return S.spheres_scene(10000, seed=355), S.spheres_shader(8), S.default_camera(w, h), w, h
-    if name == "default_4k":
+    if name in ("default_4k", "default_bleed162_4k"):
         w, h = 3840, 2160
         return S.default_scene(), S.default_shader(1), S.default_camera(w, h), w, h
     if name == "mesh100k_2lights_4k":
@@ -60,6 +61,15 @@ def build_workload(name: str):
         w, h = 640, 360
         return S.spheres_scene(1000, seed=355), S.spheres_shader(2), S.default_camera(w, h), w, h
     raise SystemExit(f"unknown workload {name}")
+
+
+def gather_of(name: str):
+    """(shading, direction set) of a workload: the renderer HEAD of the reference selects (CalcSubPixel2 with
+    shading3, main.cpp:205) on a 162-direction set (an icosahedron subdivided twice), or Shader::shading."""
+    from raytracer_amd import binding as B
+    if name == "default_bleed162_4k":
+        return B.SHADING_BLEED, B.geodesic(B.icosphere(2))
+    return B.SHADING_LIGHTS, None
 
 
 def algorithmic_flops(scene, shader, cam, stats) -> float:
@@ -88,10 +98,11 @@ def algorithmic_flops(scene, shader, cam, stats) -> float:
             back = ((nrm * (lp - pc)).sum(axis=1) < 0).sum()
             per_ray_shadow[k] += back * ALGO_FLOPS["tri_front"] + (len(tris) - back) * ALGO_FLOPS["tri_culled"]
     shadow_per_light = stats["shadow_rays"] / max(1, n_lights)
-    return stats["primary_rays"] * per_ray_primary + sum(shadow_per_light * f for f in per_ray_shadow)
+    gather = stats.get("gather_rays", 0) * base  # gather rays meet every object (scenes without meshes only)
+    return stats["primary_rays"] * per_ray_primary + sum(shadow_per_light * f for f in per_ray_shadow) + gather
 
 
-def cpu_baseline(scene, shader, cam, w, h, stride, threads):
+def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None):
     """The CPU checker (oracle/rt_oracle.c, a port of the reference path) timed on a strided pixel sample of
     the same frame, all `threads` cores and one; and, where the harness around the reference's own classes was
     built (oracle/_ref), that code on a few rows of the same frame, one thread as the reference runs."""
@@ -100,34 +111,37 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads):
     O = Oracle()
     p = scene.pack()
     t0 = time.perf_counter()
-    _, st = O.render(p, cam, shader, B.opts(w, h), threads=threads, stride=stride)
+    _, st = O.render(p, cam, shader, B.opts(w, h, shading=shading), threads=threads, stride=stride, dirs=dirs)
     dt = time.perf_counter() - t0
-    rays = st["primary_rays"] + st["shadow_rays"]
+    count = lambda q: q["primary_rays"] + q["shadow_rays"] + q["gather_rays"]
+    rays = count(st)
     out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
-                     f"{st['shadow_rays']} shadow rays, {dt:.2f} s)"}
+                     f"{st['shadow_rays']} shadow + {st['gather_rays']} gather rays, {dt:.2f} s)"}
     # one thread of the same port, on a sample a thread finishes in seconds
     s1 = stride * (4 if scene.n_primitives >= 1000 else 1)
     t0 = time.perf_counter()
-    _, st1 = O.render(p, cam, shader, B.opts(w, h), threads=1, stride=s1)
+    _, st1 = O.render(p, cam, shader, B.opts(w, h, shading=shading), threads=1, stride=s1, dirs=dirs)
     dt1 = time.perf_counter() - t0
-    out["one_thread"] = {"value": (st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6, "unit": "Mrays/s",
+    out["one_thread"] = {"value": count(st1) / dt1 / 1e6, "unit": "Mrays/s",
                          "sample": f"every {s1}th pixel in x and y ({dt1:.2f} s)"}
     # the reference's own classes (CalcIntersect, Shader::shading, Color ...) driven by the harness, one thread
     work = scene.n_primitives * (1 + len(shader.lights))
     rows = 64 if work < 200 else (1 if work < 200_000 else 0)
+    if shading:
+        rows = 16
     if Reference.available() and rows:
         R = Reference()
-        o = B.opts(w, h, row_begin=h // 2, row_end=h // 2 + rows)
-        _, sts = O.render(p, cam, shader, o, threads=threads)  # the slab's ray counts
+        o = B.opts(w, h, row_begin=h // 2, row_end=h // 2 + rows, shading=shading)
+        _, sts = O.render(p, cam, shader, o, threads=threads, dirs=dirs)  # the slab's ray counts
         t0 = time.perf_counter()
-        R.render(p, cam, shader, o)
+        R.render(p, cam, shader, o, dirs=dirs)
         dtr = time.perf_counter() - t0
         out["reference_classes_one_thread"] = {
-            "value": (sts["primary_rays"] + sts["shadow_rays"]) / dtr / 1e6, "unit": "Mrays/s", "kind": "reference",
+            "value": count(sts) / dtr / 1e6, "unit": "Mrays/s", "kind": "reference",
             "sample": f"rows {h // 2}..{h // 2 + rows - 1} of the same frame ({sts['primary_rays']} primary + "
-                      f"{sts['shadow_rays']} shadow rays, {dtr:.2f} s); the harness compiles the reference's headers, "
-                      f"main.cpp itself needs GLUT"}
+                      f"{sts['shadow_rays']} shadow + {sts['gather_rays']} gather rays, {dtr:.2f} s); the harness "
+                      f"compiles the reference's headers, main.cpp itself needs GLUT"}
     return out
 
 
@@ -185,14 +199,17 @@ def measure(name, args, ctx, headline):
     dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
 
     scene, shader, cam, w, h = build_workload(name)
+    shading, dirs = gather_of(name)
     r = Renderer(scene)
+    if dirs is not None:
+        r.set_directions(dirs)
     fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     mode = B.MODE_PACKET if args.mode == "packet" else B.MODE_ALLPAIRS
     if args.shard == "slabs" and world > 1:
         b, e = slab_rows(h, world)[rank]
-        o = B.opts(w, h, row_begin=b, row_end=e, mode=mode)
+        o = B.opts(w, h, row_begin=b, row_end=e, mode=mode, shading=shading)
     else:
-        o = B.opts(w, h, mode=mode)
+        o = B.opts(w, h, mode=mode, shading=shading)
     stream = torch.cuda.current_stream().cuda_stream
     gather = (lambda: gather_frame(fb, rank, world, dst=0)) if (args.shard == "slabs" and world > 1) else None
 
@@ -207,7 +224,7 @@ def measure(name, args, ctx, headline):
     _, stats = run_frames(r, cam, shader, o, fb, stream, args.steps, gather)
     barrier()
     dt = time.perf_counter() - t0
-    rays_step = float(stats["primary_rays"] + stats["shadow_rays"])
+    rays_step = float(stats["primary_rays"] + stats["shadow_rays"] + stats["gather_rays"])
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -241,7 +258,10 @@ def measure(name, args, ctx, headline):
            "ms_per_step": round(ms_per_step, 4),
            "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives,
                       "lights": len(shader.lights), "alias": 0, "shard": args.shard, "search": args.mode,
-                      "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"]},
+                      "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"],
+                                         "gather": stats["gather_rays"]},
+                      "shading": {0: "Shader::shading", 1: "Shader::shading2", 2: "Shader::shading3"}[shading],
+                      "gather_directions": 0 if dirs is None else len(dirs),
                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
                       "packet_survivors": stats["packet_survivors"]}}
     # ---- kernel-time breakdown: a few more frames, HIP-event times read back after each
@@ -268,7 +288,7 @@ def measure(name, args, ctx, headline):
         flops = algorithmic_flops(scene, shader, cam, stats)
         avg_ms = acc["primary_ms"] / K
         tf = flops / (avg_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_direct", "achieved": round(tf, 3),
+        out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_gather" if shading else "k_render_direct", "achieved": round(tf, 3),
                            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 5),
                            "traffic": None, "launches_per_frame": 1, "avg_launch_ms": round(avg_ms, 4),
                            "algorithmic_flops_per_frame": flops, "flops_per_test": ALGO_FLOPS,
@@ -310,13 +330,15 @@ def measure(name, args, ctx, headline):
         if stride == 0:
             work = scene.n_primitives * (1 + len(shader.lights))
             stride = 1 if work < 200 else (4 if work < 5000 else 16)
-        out["cpu_baseline"] = cpu_baseline(scene, shader, cam, w, h, stride, threads)
+        if shading:
+            stride = 4
+        out["cpu_baseline"] = cpu_baseline(scene, shader, cam, w, h, stride, threads, shading, dirs)
     r.close()
     return out
 
 
 HEADLINE = "default_4k"
-OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k"]
+OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "default_bleed162_4k"]
 
 
 def main():
@@ -365,7 +387,7 @@ def main():
         for name in OTHERS:
             others[name] = measure(name, args, ctx, headline=False)
     if rank == 0:
-        out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",
+        out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160",  # gather rays counted too where a workload casts them "value": head["value"], "unit": "Mrays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
                "higher_is_better": True, "scaling": "weak" if (args.shard == "frames" or world == 1) else "strong",
                "vs_baseline": None, "dtype": "f64" if head["kernel_time"]["search_ms_per_frame"] == 0 else "f32 search + f64 resolve",

@@ -121,6 +121,15 @@ typedef struct rt355_shader {
 #define RT355_MODE_PACKET   2 /* as ALLPAIRS, but a workgroup first culls the primitive table against
                                  the beam of its 1024 neighbouring rays; the default of the hosts     */
 
+/* Which of the reference's shaders colours a hit.  HEAD of the reference calls CalcSubPixel2 with
+ * shading3 (main.cpp:205,313,331); CalcSubPixel with Shader::shading is the variant commented out beside
+ * it (main.cpp:312,330).  The two gather shaders cast one ray per direction of the scene's direction set
+ * (rt355_scene_set_directions) from every hit and use neither lights, textures nor reflection. */
+#define RT355_SHADING_LIGHTS    0 /* CalcSubPixel + Shader::shading (main.cpp:42-158, shader.h:42-96)           */
+#define RT355_SHADING_OCCLUSION 1 /* CalcSubPixel2 (main.cpp:163-209) + Shader::shading2, ambient occlusion
+                                     (shader.h:100-140)                                                       */
+#define RT355_SHADING_BLEED     2 /* CalcSubPixel2 + Shader::shading3, colour bleeding (shader.h:143-191)       */
+
 typedef struct rt355_opts {
     int32_t width, height; /* the reference's globals (main.cpp:33)                         */
     int32_t alias;         /* setPixels' third argument: 0 = one ray through the pixel corner
@@ -129,8 +138,8 @@ typedef struct rt355_opts {
     int32_t row_begin;     /* slab [row_begin,row_end) of rows to render; 0,0 = whole frame */
     int32_t row_end;
     int32_t mode;          /* RT355_MODE_*                                                  */
-    uint32_t seed;         /* alias > 0: seed of the jitter                                 */
-    int32_t reserved;      /* 0                                                             */
+    uint32_t seed;         /* seed of the jitter (alias > 0) and of the gather rotation     */
+    int32_t shading;       /* RT355_SHADING_*                                               */
 } rt355_opts;
 
 /* The jitter of CalcPixel.  The reference draws `(double)rand() / RAND_MAX` twice per sub-sample
@@ -160,6 +169,19 @@ RT355_INLINE double rt355x_jitter(uint32_t seed, int32_t x, int32_t y, int32_t s
     return (double)(z >> 33) / 2147483647.0;
 }
 
+/* The random rotation of the gather shaders.  shading2 / shading3 draw `(double)rand() / RAND_MAX` twice
+ * per shaded hit (shader.h:106-107,149-150) and turn the direction set by theta = value * 2 * PI about z
+ * and then about x; like the jitter, the value comes from the counter-based generator instead, keyed by the
+ * sub-sample the hit belongs to.  axis 0 = random1, 1 = random2. */
+RT355_INLINE double rt355x_rotation(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t axis) {
+    uint64_t z = rt355x_mix64((uint64_t)seed);
+    z = rt355x_mix64(z ^ (uint64_t)(uint32_t)x);
+    z = rt355x_mix64(z ^ (uint64_t)(uint32_t)y);
+    z = rt355x_mix64(z ^ (((uint64_t)(uint32_t)sample << 1) | (uint64_t)(axis & 1)));
+    z = rt355x_mix64(z ^ 0x726f74617465ull);
+    return (double)(z >> 33) / 2147483647.0;
+}
+
 typedef struct rt355_stats {
     uint64_t primary_rays;   /* camera rays cast                                            */
     uint64_t shadow_rays;    /* shadow rays cast: (hit, light) pairs with N.L > 0           */
@@ -170,6 +192,7 @@ typedef struct rt355_stats {
     uint64_t packet_survivors; /* RT355_MODE_PACKET: (wave, primitive) pairs that passed both beam tests */
     uint64_t primary_hits;   /* camera rays that hit something                              */
     uint64_t secondary_rays; /* reflection rays cast (main.cpp:97-108)                      */
+    uint64_t gather_rays;    /* gather rays cast: directions with ray . nh > 0 (shader.h:122,167) */
 } rt355_stats;
 
 typedef struct rt355_scene rt355_scene; /* opaque, library-owned, bound to one HIP device */
@@ -214,6 +237,8 @@ int rt355_scene_resolve_launch_ms(rt355_scene *scene, int32_t index, double *ms)
  * and zeros on a miss).  Mirrors AnyObject::CalcIntersect (anyobject.h:23) one call at a time so
  * the device arithmetic can be checked in isolation. */
 int rt355_probe_intersect(rt355_scene *scene, int obj, const double *rays, int n, double *out);
+/* Debug probe: rt355_sincos evaluated on the device for n arguments -> n x 2 doubles (sin, cos). */
+int rt355_probe_sincos(const double *x, int n, double *out);
 
 /* HIP-event duration (ms) of the index-th candidate-search launch of the last synced render
  * (0 = camera rays; then, per group of lights, one launch for the lights with a position and one
@@ -223,8 +248,19 @@ int rt355_scene_search_launch_ms(rt355_scene *scene, int32_t index, double *ms);
 const char *rt355_last_error(void);
 int rt355_abi_version(void);
 
-/* rt355x_jitter as an exported function. */
+/* rt355x_jitter and rt355x_rotation as exported functions. */
 double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim);
+double rt355_rotation(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t axis);
+
+/* The direction set of the gather shaders: the global `geo` that main.cpp:557 fills from Geodesic()
+ * (main.cpp:408-450: the `v` lines of an OBJ file, centred on their mean and normalised).  xyz holds n
+ * directions as the reference holds them after that function; they are copied.  n = 0 clears the set
+ * (every hit then comes out black, as 0/0 does in shader.h:137,188). */
+int rt355_scene_set_directions(rt355_scene *scene, const double *xyz, int32_t n);
+
+/* sin and cos as the device computes them for the gather rotation: correctly rounded (double-double
+ * evaluation), 0 <= x < 8.  Runs on the host; for checks against a C library. */
+int rt355_sincos(double x, double *sin_out, double *cos_out);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,23 @@ def main():
         np.save(os.path.join(OUT, fn), frame)
         meta["alias_cases"].append({"case": name, "alias": alias, "seed": seed, "width": w, "height": h, "file": fn,
                                     "fnv1a64": f"{B.fnv1a64(frame):016x}"})
+    # 1c. the gather shaders (CalcSubPixel2 with the reference's own Shader::shading3 / shading2), the two
+    #     rand() draws per hit replaced by rt355_rotation; direction sets are subdivided icosahedra
+    meta["gather_cases"] = []
+    for name, level, shading, alias in (("default_2lights", 0, B.SHADING_BLEED, 0), ("default_2lights", 2, B.SHADING_BLEED, 0),
+                                        ("default_2lights", 1, B.SHADING_OCCLUSION, 0), ("mesh", 1, B.SHADING_BLEED, 2),
+                                        ("inside", 1, B.SHADING_OCCLUSION, 2), ("textured", 1, B.SHADING_BLEED, 0),
+                                        ("mirrors_mesh", 0, B.SHADING_BLEED, 0)):
+        sc, sh, cam, w, h = S.small_case(name)
+        w, h = w // 2, h // 2
+        cam = S.default_camera(w, h)
+        seed = 5000 + 10 * level + shading
+        dirs = B.geodesic(B.icosphere(level))
+        frame = R.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=seed, shading=shading), dirs=dirs)
+        fn = f"frame_{name}_gather{shading}_l{level}_a{alias}.npy"
+        np.save(os.path.join(OUT, fn), frame)
+        meta["gather_cases"].append({"case": name, "level": level, "shading": shading, "alias": alias, "seed": seed,
+                                     "width": w, "height": h, "file": fn, "fnv1a64": f"{B.fnv1a64(frame):016x}"})
     # 2. CalcIntersect known answers: rays aimed roughly at each object kind
     sc, _, _, _, _ = S.small_case("mesh")
     p = sc.pack()

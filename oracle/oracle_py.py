@@ -27,6 +27,13 @@ class Oracle:
         L.rt_oracle_render.restype = C.c_int
         L.rt_oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int]
+        L.rt_oracle_render_gather.restype = C.c_int
+        L.rt_oracle_render_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.rt_oracle_sincos.restype = None
+        L.rt_oracle_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.rt_oracle_sincos_rounded.restype = None
+        L.rt_oracle_sincos_rounded.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_oracle_fnv1a64.restype = C.c_uint64
         L.rt_oracle_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         L.rt_oracle_intersect.restype = C.c_int
@@ -37,16 +44,24 @@ class Oracle:
         L.rt_oracle_texture.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
         self.L = L
 
-    def render(self, packed, cam, shader, o: COpts, threads=0, stride=1, out=None):
-        """Returns (pixmap (H,W,3) uint8, stats dict)."""
+    def render(self, packed, cam, shader, o: COpts, threads=0, stride=1, out=None, dirs=None):
+        """Returns (pixmap (H,W,3) uint8, stats dict).  dirs: the gather shaders' direction set, (n, 3) float64."""
         if out is None:
             out = np.zeros((o.height, o.width, 3), dtype=np.uint8)
         st = CStats()
-        rc = self.L.rt_oracle_render(C.byref(packed.desc), C.byref(cam), C.byref(shader.c), C.byref(o),
-                                     out.ctypes.data, C.byref(st), threads, stride)
+        d = np.ascontiguousarray(dirs if dirs is not None else np.zeros((0, 3)), dtype=np.float64).reshape(-1, 3)
+        rc = self.L.rt_oracle_render_gather(C.byref(packed.desc), C.byref(cam), C.byref(shader.c), C.byref(o),
+                                            d.ctypes.data if len(d) else None, len(d),
+                                            out.ctypes.data, C.byref(st), threads, stride)
         if rc != 0:
             raise RuntimeError(f"rt_oracle_render failed: {rc}")
         return out, st.as_dict()
+
+    def sincos(self, x: float, rounded=False):
+        """The C library's sin and cos, or (rounded) the correctly rounded ones from binary128."""
+        sv, cv = C.c_double(), C.c_double()
+        (self.L.rt_oracle_sincos_rounded if rounded else self.L.rt_oracle_sincos)(float(x), C.byref(sv), C.byref(cv))
+        return sv.value, cv.value
 
     def fnv(self, arr: np.ndarray) -> int:
         a = np.ascontiguousarray(arr)
@@ -88,6 +103,8 @@ class Reference:
         L = C.CDLL(path)
         L.ref_render.restype = C.c_int
         L.ref_render.argtypes = [C.c_void_p] * 5 + [C.c_char_p]
+        L.ref_render_gather.restype = C.c_int
+        L.ref_render_gather.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_char_p]
         L.ref_intersect_many.restype = C.c_int
         L.ref_intersect_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p]
         L.ref_color_op.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
@@ -103,10 +120,11 @@ class Reference:
     def available() -> bool:
         return os.path.exists(REF_SO)
 
-    def render(self, packed, cam, shader, o: COpts):
+    def render(self, packed, cam, shader, o: COpts, dirs=None):
         out = np.zeros((o.height, o.width, 3), dtype=np.uint8)
-        rc = self.L.ref_render(C.byref(packed.desc), C.byref(cam), C.byref(shader.c), C.byref(o),
-                               out.ctypes.data, self.tmp.encode())
+        d = np.ascontiguousarray(dirs if dirs is not None else np.zeros((0, 3)), dtype=np.float64).reshape(-1, 3)
+        rc = self.L.ref_render_gather(C.byref(packed.desc), C.byref(cam), C.byref(shader.c), C.byref(o),
+                                      d.ctypes.data if len(d) else None, len(d), out.ctypes.data, self.tmp.encode())
         if rc != 0:
             raise RuntimeError(f"ref_render failed: {rc}")
         return out

@@ -17,12 +17,42 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
 #include <tuple>
 #include <vector>
+
+// Shader::shading2 / shading3 draw their two rotation angles with rand() (shader.h:106-107,149-150).  Inside
+// the reference's headers that name is pointed at the harness's own source of numbers, which hands out the
+// counter-based values of rt355_rotation for the sub-sample being shaded -- the one change of input that
+// lets frames be compared pixel by pixel.  The standard headers are included above, so only the
+// reference's code sees the macro.
+// Their sin() and cos() (shader.h:115,119,160,164; nothing else on the path calls them) are pointed at
+// correctly rounded evaluations: the C library's last bit differs between libraries, and a gather ray that
+// starts on a sphere's surface hits or misses that sphere by the sign of a rounding error.
+#include <quadmath.h>
+static int rt355_harness_rand();
+// (the reference asks for the same two angles once per direction: the last two are remembered)
+static double rt355_harness_trig(double x, int want_cos) {
+    static thread_local struct { double x, s, c; bool set; } memo[2];
+    static thread_local int next = 0;
+    for (int i = 0; i < 2; i++)
+        if (memo[i].set && memo[i].x == x) return want_cos ? memo[i].c : memo[i].s;
+    memo[next].x = x; memo[next].s = (double)sinq((__float128)x); memo[next].c = (double)cosq((__float128)x);
+    memo[next].set = true;
+    const double r = want_cos ? memo[next].c : memo[next].s;
+    next ^= 1;
+    return r;
+}
+static double rt355_harness_sin(double x) { return rt355_harness_trig(x, 0); }
+static double rt355_harness_cos(double x) { return rt355_harness_trig(x, 1); }
+#define rand rt355_harness_rand
+#define sin rt355_harness_sin
+#define cos rt355_harness_cos
 
 // same order as main.cpp:17-21
 #include "vector3D.h"
@@ -31,8 +61,20 @@
 #include "shader.h"
 #include "anyobject.h"
 
+#undef rand
+#undef sin
+#undef cos
+
 #include "../include/rt355.h"
 #include "../include/rt355_reference_adaptor.hpp"
+
+// the sub-sample whose hit is being shaded, and how many numbers it has drawn
+static thread_local struct { uint32_t seed; int x, y, sample, drawn; } g_draw;
+static int rt355_harness_rand() {
+    // rt355_rotation returns value / RAND_MAX with value a 31-bit integer; hand that integer back
+    const double v = rt355x_rotation(g_draw.seed, g_draw.x, g_draw.y, g_draw.sample, g_draw.drawn++);
+    return (int)(v * 2147483647.0 + 0.5);
+}
 
 namespace {
 
@@ -184,6 +226,25 @@ Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd, int refle
     return clr_reflection;
 }
 
+// CalcSubPixel2 as CalcPixel calls it (main.cpp:163-209 with outside = 1), re-expressed; the shader call is the
+// reference's own Shader::shading3 (main.cpp:205) or Shader::shading2.
+Color sub_pixel2(View eye, std::vector<AnyObject *> &objs, Shader &shd, std::vector<Vector3D> &geo, int shading) {
+    double t_min = FLT_MAX;
+    Color clr = Color(0, 0, 0);
+    Color cm0(0, 0, 0);
+    Point3D ph(0, 0, 0);
+    Vector3D nh(0, 0, 0);
+    for (int i = 0; i < (int)objs.size(); i++) {
+        tuple<Color, double, Point3D, Vector3D, int> r = objs[i]->CalcIntersect(eye);
+        double t = get<1>(r);
+        if (t >= 0 && t < t_min) { t_min = t; cm0 = get<0>(r); ph = get<2>(r); nh = get<3>(r); }
+    }
+    if (t_min != FLT_MAX)
+        clr = (shading == RT355_SHADING_BLEED) ? shd.shading3(cm0, shd.ambient_color, ph, nh, objs, geo)
+                                               : shd.shading2(cm0, shd.ambient_color, ph, nh, objs, geo);
+    return clr;
+}
+
 std::vector<light_src *> make_lights(const rt355_shader *sh) {
     std::vector<light_src *> ls;
     for (int i = 0; i < sh->n_lights; i++) {
@@ -199,8 +260,24 @@ std::vector<light_src *> make_lights(const rt355_shader *sh) {
 
 extern "C" {
 
+int ref_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
+                      const rt355_opts *opts, const double *dirs, int n_dirs, unsigned char *pixmap,
+                      const char *tmpdir);
 int ref_render(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
                const rt355_opts *opts, unsigned char *pixmap, const char *tmpdir) {
+    return ref_render_gather(d, cam, sh, opts, nullptr, 0, pixmap, tmpdir);
+}
+int ref_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
+                      const rt355_opts *opts, const double *dirs, int n_dirs, unsigned char *pixmap,
+                      const char *tmpdir) {
+    std::vector<Vector3D> geo;
+    for (int i = 0; i < n_dirs; i++) geo.push_back(Vector3D(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
+    const int shading = opts->shading;
+    auto shade = [&](View eye, std::vector<AnyObject *> &objs, Shader &shd, int x, int y, int sample) {
+        if (shading == RT355_SHADING_LIGHTS) return sub_pixel(eye, objs, shd);
+        g_draw.seed = opts->seed; g_draw.x = x; g_draw.y = y; g_draw.sample = sample; g_draw.drawn = 0;
+        return sub_pixel2(eye, objs, shd, geo, shading);
+    };
     RefScene rs;
     if (!build(d, tmpdir, rs)) return -1;
     std::vector<light_src *> ls = make_lights(sh);
@@ -222,14 +299,14 @@ int ref_render(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_s
                         double pointX = (rt355x_jitter(opts->seed, x, y, q * alias + p, 0) + p) / alias + x;
                         double pointY = (rt355x_jitter(opts->seed, x, y, q * alias + p, 1) + q) / alias + y;
                         View eye = calc_view(k, pointX / W, pointY / H);
-                        Color clr_sub = sub_pixel(eye, rs.objs, shd);
+                        Color clr_sub = shade(eye, rs.objs, shd, x, y, q * alias + p);
                         red += clr_sub.r; green += clr_sub.g; blue += clr_sub.b;
                     }
                 red = red / (alias * alias); green = green / (alias * alias); blue = blue / (alias * alias);
                 c = Color(red, green, blue);
             } else {
                 View eye = calc_view(k, (double)x / W, (double)y / H);
-                c = sub_pixel(eye, rs.objs, shd);
+                c = shade(eye, rs.objs, shd, x, y, 0);
             }
             size_t i = ((size_t)y * W + x) * 3;
             pixmap[i] = c.r; pixmap[i + 1] = c.g; pixmap[i + 2] = c.b;

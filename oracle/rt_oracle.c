@@ -17,6 +17,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include <quadmath.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -260,6 +261,9 @@ typedef struct {
     const rt355_shader *sh;
     uint64_t shadow_rays;
     uint64_t secondary_rays;
+    const double *dirs; /* geo, main.cpp:557 */
+    int n_dirs;
+    uint64_t gather_rays;
 } octx;
 
 static col calc_diffuse(const rt355_light *L, col cm0, col cm1, v3 nh, v3 nhl) { /* shader.h:324-338 */
@@ -366,6 +370,82 @@ static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double ref
 }
 static col calc_subpixel(octx *cx, ray eye) { return calc_subpixel_rec(cx, eye, 0, 1.0); }
 
+/* sin and cos of the gather rotation, correctly rounded (evaluated in binary128 by libquadmath, rounded
+ * once).  The reference calls its C library's sin and cos; those differ between libraries in the last bit
+ * (glibc's are within 0.55 ulp, not correctly rounded), and a gather ray that starts on a sphere's surface
+ * hits or misses that sphere by the sign of a rounding error, so a last-bit change of the rotation does
+ * change pixels.  The path is therefore defined on the correctly rounded functions, which every
+ * implementation can reproduce. */
+static double sin_cr(double x) { return (double)sinq((__float128)x); }
+static double cos_cr(double x) { return (double)cosq((__float128)x); }
+
+/* Shader::shading2 (bleed == 0, shader.h:100-140) and Shader::shading3 (bleed == 1, shader.h:143-191).
+ * random1 / random2 are the two `(double)rand() / RAND_MAX` draws, taken from rt355_rotation by the caller. */
+static col shading_gather(octx *cx, int bleed, col cm0, col cm1, v3 ph, v3 nh, double random1, double random2) {
+    int len = cx->n_dirs;
+    int cnt = 0;
+    double theta1 = random1 * 2 * REF_PI;
+    double theta2 = random2 * 2 * REF_PI;
+    col clr_tmp = C(0, 0, 0);
+    v3 clr_sum = V(0, 0, 0);
+    int obj_nmb = cx->s->d->n_objects;
+    /* the reference evaluates these inside the loop; they do not change there */
+    const double s1 = sin_cr(theta1), c1 = cos_cr(theta1), s2 = sin_cr(theta2), c2 = cos_cr(theta2);
+    for (int i = 0; i < len; i++) {
+        double x = cx->dirs[3 * i], y = cx->dirs[3 * i + 1], z = cx->dirs[3 * i + 2];
+        v3 r = V(c1 * x - s1 * y, s1 * x + c1 * y, z);          /* shader.h:115,160 */
+        x = r.x; y = r.y; z = r.z;
+        r = V(x, c2 * y - s2 * z, s2 * y + c2 * z);             /* :119,164 */
+        if (dot(r, nh) <= 0) continue;
+        cx->gather_rays++;
+        ray vw = mkview(ph, r);
+        if (!bleed) {
+            for (int j = 0; j < obj_nmb; j++) {
+                hit h = obj_isect(cx->s, j, vw);
+                if (h.t > 0) { cnt += 2; break; }
+            }
+            continue;
+        }
+        double t_min = FLT_MAX;
+        for (int j = 0; j < obj_nmb; j++) {
+            hit h = obj_isect(cx->s, j, vw);
+            if (h.t > 0 && h.t < t_min) {
+                t_min = h.t;
+                const rt355_object *o = &cx->s->d->objects[j]; /* get<0>: the object's clr (anyobject.h:86,156,517) */
+                clr_tmp = C(o->rgb[0], o->rgb[1], o->rgb[2]);
+            }
+        }
+        if (t_min < 100) {
+            clr_sum = V(clr_sum.x + clr_tmp.r, clr_sum.y + clr_tmp.g, clr_sum.z + clr_tmp.b);
+            cnt += 2;
+        }
+    }
+    if (bleed) cm1 = C(q8(clr_sum.x / cnt), q8(clr_sum.y / cnt), q8(clr_sum.z / cnt)); /* :187 */
+    return cadd(cmul(cm0, 1 - cnt * 1.0 / len), cmul(cm1, cnt * 1.0 / len));           /* :137,188 */
+}
+
+/* CalcSubPixel2, main.cpp:163-209, as CalcPixel calls it (outside = 1, so the branch at :174 is not taken);
+ * `shading` is 2 for the shading3 call of :205, 1 for shading2 in its place. */
+static col calc_subpixel2(octx *cx, ray eye, int shading, uint32_t seed, int px, int py, int sample) {
+    int n = cx->s->d->n_objects;
+    double t_min = FLT_MAX;
+    hit best; memset(&best, 0, sizeof best);
+    int idx = 0;
+    col clr = C(0, 0, 0);
+    for (int i = 0; i < n; i++) {
+        hit h = obj_isect(cx->s, i, eye);
+        if (h.t >= 0 && h.t < t_min) { t_min = h.t; idx = i; best = h; }
+    }
+    if (t_min != FLT_MAX) {
+        const rt355_object *o = &cx->s->d->objects[idx];
+        const rt355_shader *sh = cx->sh;
+        clr = shading_gather(cx, shading == RT355_SHADING_BLEED, C(o->rgb[0], o->rgb[1], o->rgb[2]),
+                             C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), best.ph, best.nh,
+                             rt355x_rotation(seed, px, py, sample, 0), rt355x_rotation(seed, px, py, sample, 1));
+    }
+    return clr;
+}
+
 typedef struct { v3 p_eye, n0, n1, p00; double s_x, s_y; } ocam;
 /* Scene::SetCamera, main.cpp:255-262 */
 static ocam set_camera(const rt355_camera *c) {
@@ -408,9 +488,18 @@ static int oscene_init(oscene *s, const rt355_scene_desc *d) {
  * `stride` > 1 renders only pixels with x % stride == 0 and y % stride == 0 (the rays
  * are the same as the full frame's; other pixels are left untouched) -- used to time a
  * bounded sample.  n_threads <= 0 = all cores; rows are interleaved over threads. */
+int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
+                            const rt355_opts *opts, const double *dirs, int n_dirs, unsigned char *pixmap,
+                            rt355_stats *stats, int n_threads, int stride);
 int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
                      const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats,
                      int n_threads, int stride) {
+    return rt_oracle_render_gather(d, cam, sh, opts, NULL, 0, pixmap, stats, n_threads, stride);
+}
+/* The same with the direction set `geo` of the gather shaders (opts->shading != RT355_SHADING_LIGHTS). */
+int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
+                            const rt355_opts *opts, const double *dirs, int n_dirs, unsigned char *pixmap,
+                            rt355_stats *stats, int n_threads, int stride) {
     if (!d || !cam || !sh || !opts || !pixmap) return RT355_ERR_ARG;
     if (opts->alias < 0) return RT355_ERR_ARG;
     oscene s;
@@ -420,17 +509,19 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
     int y0 = opts->row_begin, y1 = opts->row_end;
     if (y0 == 0 && y1 == 0) y1 = H;
     if (stride < 1) stride = 1;
-    uint64_t prim = 0, shad = 0, sec = 0;
+    uint64_t prim = 0, shad = 0, sec = 0, gat = 0;
+    const int shading = opts->shading;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
     (void)n_threads;
     const int y_first = (y0 + stride - 1) / stride * stride; /* sampled rows: multiples of stride; dealt out one by one */
     const int n_sampled = y_first < y1 ? (y1 - y_first + stride - 1) / stride : 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : prim, shad, sec)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : prim, shad, sec, gat)
     for (int j = 0; j < n_sampled; j++) {
         const int y = y_first + j * stride;
         octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0; cx.secondary_rays = 0;
+        cx.dirs = dirs; cx.n_dirs = n_dirs; cx.gather_rays = 0;
         const int alias = opts->alias;
         for (int x = 0; x < W; x += stride) {
             col clr;
@@ -441,7 +532,8 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
                         double pointX = (rt355x_jitter(opts->seed, x, y, q * alias + p, 0) + p) / alias + x; /* :292 */
                         double pointY = (rt355x_jitter(opts->seed, x, y, q * alias + p, 1) + q) / alias + y; /* :293 */
                         ray eye = calc_view(&c, pointX / W, pointY / H);
-                        col sub = calc_subpixel(&cx, eye);
+                        col sub = shading ? calc_subpixel2(&cx, eye, shading, opts->seed, x, y, q * alias + p)
+                                          : calc_subpixel(&cx, eye);
                         red += sub.r; green += sub.g; blue += sub.b;                                         /* :315-317 */
                         prim++;
                     }
@@ -449,7 +541,7 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
                 clr = C(q8(red), q8(green), q8(blue));                                                        /* :325 */
             } else {
                 ray eye = calc_view(&c, (double)x / W, (double)y / H);
-                clr = calc_subpixel(&cx, eye);
+                clr = shading ? calc_subpixel2(&cx, eye, shading, opts->seed, x, y, 0) : calc_subpixel(&cx, eye);
                 prim++;
             }
             size_t i = ((size_t)y * W + x) * 3;
@@ -457,6 +549,7 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
         }
         shad += cx.shadow_rays;
         sec += cx.secondary_rays;
+        gat += cx.gather_rays;
     }
     free(s.tris);
     if (stats) {
@@ -464,6 +557,7 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
         stats->primary_rays = prim;
         stats->shadow_rays = shad;
         stats->secondary_rays = sec;
+        stats->gather_rays = gat;
     }
     return RT355_OK;
 }
@@ -473,6 +567,10 @@ int rt_oracle_render(const rt355_scene_desc *d, const rt355_camera *cam, const r
 double rt_oracle_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim) {
     return rt355x_jitter(seed, x, y, sample, dim);
 }
+/* the C library's sin and cos, as the reference's shading2 / shading3 call them, and the correctly rounded
+ * ones the gather path is defined on */
+void rt_oracle_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
+void rt_oracle_sincos_rounded(double x, double *s, double *c) { *s = sin_cr(x); *c = cos_cr(x); }
 
 
 /* Camera ray of pixel (x,y): out[0..2] = pe, out[3..5] = npe. */

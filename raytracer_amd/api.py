@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from .binding import ERR, MODE_PACKET, CStats, COpts, PackedScene, Scene, Shader, opts as make_opts
+from .binding import ERR, MODE_PACKET, SHADING_LIGHTS, CStats, COpts, PackedScene, Scene, Shader, opts as make_opts
 
 _LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt355.so")
 _lib = None
@@ -41,6 +41,9 @@ def lib():
         L.rt355_scene_resolve_launch_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
         L.rt355_scene_search_launch_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
         L.rt355_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.rt355_probe_sincos.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rt355_scene_set_directions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.rt355_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -72,15 +75,21 @@ class Renderer:
             pass
 
     def render(self, cam, shader: Shader, width: int, height: int, alias=0, row_begin=0, row_end=0,
-               mode=MODE_PACKET, out: np.ndarray | None = None, seed=0):
+               mode=MODE_PACKET, out: np.ndarray | None = None, seed=0, shading=SHADING_LIGHTS):
         """Host framebuffer path (rt355_render).  Returns (pixmap (H,W,3) uint8, stats dict)."""
-        o = make_opts(width, height, alias, row_begin, row_end, mode, seed)
+        o = make_opts(width, height, alias, row_begin, row_end, mode, seed, shading)
         if out is None:
             out = np.zeros((height, width, 3), dtype=np.uint8)
         st = CStats()
         _check(lib().rt355_render(self.handle, C.byref(cam), C.byref(shader.c), C.byref(o), out.ctypes.data,
                                   C.byref(st)), "rt355_render")
         return out, st.as_dict()
+
+    def set_directions(self, dirs):
+        """The direction set `geo` of the gather shaders (main.cpp:557), (n, 3) float64 as Geodesic() leaves it."""
+        d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        _check(lib().rt355_scene_set_directions(self.handle, d.ctypes.data if len(d) else None, len(d)),
+               "rt355_scene_set_directions")
 
     def render_device(self, cam, shader: Shader, o: COpts, d_pixmap: int, stream: int = 0):
         """Device framebuffer path (rt355_render_device): enqueue only; call sync() for stats."""
@@ -128,3 +137,18 @@ class Renderer:
         _check(lib().rt355_probe_intersect(self.handle, obj, rays.ctypes.data, len(rays), out.ctypes.data),
                "rt355_probe_intersect")
         return out
+
+
+def sincos(x: float):
+    """rt355_sincos: the correctly rounded sin and cos the device uses for the gather rotation (host evaluation)."""
+    sv, cv = C.c_double(), C.c_double()
+    _check(lib().rt355_sincos(float(x), C.byref(sv), C.byref(cv)), "rt355_sincos")
+    return sv.value, cv.value
+
+
+def probe_sincos(x) -> np.ndarray:
+    """rt355_probe_sincos: the same function evaluated on the device; (n, 2) float64 (sin, cos)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    out = np.zeros((len(x), 2), dtype=np.float64)
+    _check(lib().rt355_probe_sincos(x.ctypes.data, len(x), out.ctypes.data), "rt355_probe_sincos")
+    return out

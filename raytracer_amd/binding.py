@@ -16,6 +16,7 @@ import numpy as np
 
 OBJ_PLANE, OBJ_SPHERE, OBJ_MESH = 0, 1, 2
 MODE_ALLPAIRS, MODE_BRUTE, MODE_PACKET = 0, 1, 2
+SHADING_LIGHTS, SHADING_OCCLUSION, SHADING_BLEED = 0, 1, 2
 
 ERR = {0: "OK", -1: "ERR_ARG", -2: "ERR_UNSUPPORTED", -3: "ERR_DEVICE", -4: "ERR_NOMEM"}
 
@@ -65,21 +66,21 @@ class CShader(C.Structure):
 class COpts(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("alias", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("mode", C.c_int32),
-                ("seed", C.c_uint32), ("reserved", C.c_int32)]
+                ("seed", C.c_uint32), ("shading", C.c_int32)]
 
 
 class CStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("pair_tests", C.c_uint64), ("exact_tests", C.c_uint64),
                 ("overflow_rays", C.c_uint64), ("ms_device", C.c_double), ("packet_survivors", C.c_uint64), ("primary_hits", C.c_uint64),
-                ("secondary_rays", C.c_uint64)]
+                ("secondary_rays", C.c_uint64), ("gather_rays", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 assert C.sizeof(CTexture) == 32 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
-assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 32 and C.sizeof(CStats) == 72
+assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 32 and C.sizeof(CStats) == 80
 
 
 def _normalize(v: Sequence[float]):
@@ -242,24 +243,90 @@ def camera(p_eye=(0, -20, 0), v_view=(0, 1, 0), v_up=(0, 0, 1), dist=10.0, width
     return c
 
 
-def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_PACKET, seed=0) -> COpts:
-    return COpts(width, height, alias, row_begin, row_end, mode, seed, 0)
+def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_PACKET, seed=0, shading=SHADING_LIGHTS) -> COpts:
+    return COpts(width, height, alias, row_begin, row_end, mode, seed, shading)
+
+
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _mix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def _keyed(seed, x, y, sample, dim):
+    z = _mix64(seed & 0xFFFFFFFF)
+    z = _mix64(z ^ (x & 0xFFFFFFFF))
+    z = _mix64(z ^ (y & 0xFFFFFFFF))
+    return _mix64(z ^ (((sample & 0xFFFFFFFF) << 1) | (dim & 1)))
 
 
 def jitter(seed, x, y, sample, dim) -> float:
     """rt355_jitter of include/rt355.h (the jitter of CalcPixel, main.cpp:292-293, from a counter-based generator)."""
-    M = 0xFFFFFFFFFFFFFFFF
+    return (_keyed(seed, x, y, sample, dim) >> 33) / 2147483647.0
 
-    def mix(z):
-        z = (z + 0x9E3779B97F4A7C15) & M
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
-        return z ^ (z >> 31)
-    z = mix(seed & 0xFFFFFFFF)
-    z = mix(z ^ (x & 0xFFFFFFFF))
-    z = mix(z ^ (y & 0xFFFFFFFF))
-    z = mix(z ^ (((sample & 0xFFFFFFFF) << 1) | (dim & 1)))
-    return (z >> 33) / 2147483647.0
+
+def rotation(seed, x, y, sample, axis) -> float:
+    """rt355_rotation of include/rt355.h (random1 / random2 of shading2 and shading3, shader.h:106-107,149-150)."""
+    return (_mix64(_keyed(seed, x, y, sample, axis) ^ 0x726F74617465) >> 33) / 2147483647.0
+
+
+def geodesic(vertices) -> np.ndarray:
+    """Geodesic() of main.cpp:408-450 after the file is read: the vertices minus their mean, normalised,
+    in the reference's operation order.  Returns (n, 3) float64."""
+    v = [tuple(float(c) for c in p) for p in vertices]
+    sx = sy = sz = 0.0
+    for x, y, z in v:                      # sum = sum + vertex, main.cpp:435
+        sx, sy, sz = sx + x, sy + y, sz + z
+    n = len(v)
+    if n == 0:
+        return np.zeros((0, 3), np.float64)
+    sx, sy, sz = sx / n, sy / n, sz / n    # main.cpp:443
+    out = []
+    for x, y, z in v:                      # geo[i] + (Point3D(0,0,0) - sum), then normalize(): main.cpp:446-447
+        out.append(_normalize((x + (0.0 - sx), y + (0.0 - sy), z + (0.0 - sz))))
+    return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+
+def read_geodesic(path) -> np.ndarray:
+    """The file half of Geodesic(): the `v x y z` lines of an OBJ file (main.cpp:425-440)."""
+    verts = []
+    with open(path) as f:
+        for line in f:
+            if line[:2] == "v ":
+                parts = line[2:].split()
+                verts.append((float(parts[0]), float(parts[1]), float(parts[2])))
+    return geodesic(verts)
+
+
+def icosphere(level=1):
+    """Vertices of an icosahedron subdivided `level` times (12, 42, 162, 642 ... points on the unit sphere):
+    a stand-in for the reference's geodesic.obj, which its repository does not hold."""
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+             (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    verts = [_normalize(v) for v in verts]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2),
+             (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11),
+             (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(level):
+        cache = {}
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                verts.append(_normalize(tuple((verts[a][i] + verts[b][i]) / 2.0 for i in range(3))))
+                cache[key] = len(verts) - 1
+            return cache[key]
+        nf = []
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = nf
+    return verts
 
 
 def fnv1a64(buf) -> int:

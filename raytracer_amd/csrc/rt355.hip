@@ -39,7 +39,7 @@
 #include "../../include/rt355.h"
 #include "rt_exact.h"
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 #define SEARCH_THREADS 256
 #ifndef RAYS_PER_THREAD
 #define RAYS_PER_THREAD 4   // rays per lane of the search kernel (2, 4 or 8)
@@ -1386,29 +1386,27 @@ __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const
     return n_shadow;
 }
 
-// What Shader::shading needs of the accepted hit (main.cpp:69-77, shader.h:53-58), plus the two terms of
-// its light loop that do not depend on the light: reh of CalcSpecular and the weight of CalcBorder.
-struct HitRec {
-    d3 ph, nh, reh;
-    double border_w;
-    uint32_t cm0, cm1;
+// The accepted hit as the object's CalcIntersect returns it (main.cpp:69-77): point, normal, the mesh's
+// interpolated UV.
+struct HitGeo {
+    d3 ph, nh;
+    double uvx, uvy;
     int obj;
-    bool no_border;
 };
-__device__ __forceinline__ HitRec primary_record(const SceneView &s, const ShaderView &sh, const Ray &e, const Closest &c) {
-    HitRec h;
+__device__ __forceinline__ HitGeo hit_geometry(const SceneView &s, const Ray &e, const Closest &c) {
+    HitGeo h;
     h.obj = s.prim_obj[c.prim_best];
+    h.uvx = 0; h.uvy = 0;
     const int tri = s.prim_tri[c.prim_best];
     const DObject &o = s.objects[h.obj];
-    double uvx = 0, uvy = 0;
     if (tri >= 0) {
         const DTriangle &T = s.tris[tri];
         int outside; double u, v;
         tri_t(T, e, &outside, &h.ph, &u, &v);
         h.nh = vmul(ld3(T.normal), (double)outside);                 // anyobject.h:517
         double wgt = 1 - u - v;                                      // Triangle::GetUV, anyobject.h:524-526
-        uvx = T.uv0[0] * wgt + T.uv1[0] * u + T.uv2[0] * v;
-        uvy = T.uv0[1] * wgt + T.uv1[1] * u + T.uv2[1] * v;
+        h.uvx = T.uv0[0] * wgt + T.uv1[0] * u + T.uv2[0] * v;
+        h.uvy = T.uv0[1] * wgt + T.uv1[1] * u + T.uv2[1] * v;
     } else if (o.type == RT_OBJ_PLANE) {
         d3 ni = ld3(o.n);
         int outside = (dot(ni, vsub(e.pe, ld3(o.p))) <= 0) ? -1 : 1; // anyobject.h:71-77
@@ -1420,8 +1418,24 @@ __device__ __forceinline__ HitRec primary_record(const SceneView &s, const Shade
         h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :155
         h.nh = vmul(normalize(vsub(h.ph, ld3(o.p))), (double)outside); // :156
     }
+    return h;
+}
+// What Shader::shading needs of the accepted hit (main.cpp:69-77, shader.h:53-58), plus the two terms of
+// its light loop that do not depend on the light: reh of CalcSpecular and the weight of CalcBorder.
+struct HitRec {
+    d3 ph, nh, reh;
+    double border_w;
+    uint32_t cm0, cm1;
+    int obj;
+    bool no_border;
+};
+__device__ __forceinline__ HitRec primary_record(const SceneView &s, const ShaderView &sh, const Ray &e, const Closest &c) {
+    const HitGeo g = hit_geometry(s, e, c);
+    HitRec h;
+    h.obj = g.obj; h.ph = g.ph; h.nh = g.nh;
+    const DObject &o = s.objects[h.obj];
     h.cm0 = o.rgb; h.cm1 = sh.ambient;
-    if (o.texture_type == 1) texture_mapping(s, o, h.ph, uvx, uvy, &h.cm0, &h.cm1); // shader.h:53-58
+    if (o.texture_type == 1) texture_mapping(s, o, h.ph, g.uvx, g.uvy, &h.cm0, &h.cm1); // shader.h:53-58
     h.no_border = (o.type != RT_OBJ_SPHERE);                         // main.cpp:74
     h.reh = mirror_dir(h.nh, e.npe);
     h.border_w = h.no_border ? 0.0 : border_weight(e.pe, h.ph, h.nh);
@@ -1520,6 +1534,98 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
     if (REFLECT) wave_count(w.counters, 6, n_secondary);
+}
+
+// CalcSubPixel2 (main.cpp:163-209), the renderer HEAD of the reference selects: the closest hit as in
+// CalcSubPixel, coloured by one of the gather shaders -- shading3 (colour bleeding, shader.h:143-191) or
+// shading2 (ambient occlusion, shader.h:100-140).  Both turn the scene's direction set by two random angles
+// (about z, then about x), skip the directions with ray . nh <= 0 and cast the others from the hit point
+// against every object, taking hits with t > 0 only.  cm0 is the object's own colour as CalcIntersect
+// returns it: no texture lookup, lights, border or reflection on this path.  The angles come from
+// rt355x_rotation in place of rand().  A lane looks for its next direction that passes the normal test
+// before the wave walks the primitives together, so the lanes skipped by that test do not idle through
+// a walk.
+struct Gather { const double *dirs; int32_t n; };
+template <bool BLEED>
+__global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+                                                       Gather ga, unsigned char *__restrict__ pixmap) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_gather = 0;
+    do {
+    if (rid >= f.n_rays) break;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    if (!(x < f.grid_w && y < f.grid_h)) break;
+    const Ray e = grid_ray(cam, f, x, y);
+    Spill none; none.pool = nullptr; none.count = nullptr;
+    Closest c;
+    closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
+    uint32_t clr = 0u; // main.cpp:167,204: no hit -> Color(0,0,0)
+    if (c.prim_best >= 0) {
+        n_hit = 1;
+        const HitGeo h = hit_geometry(s, e, c);
+        const uint32_t cm0 = s.objects[h.obj].rgb;
+        // the sub-sample this hit belongs to keys the two random numbers
+        int px = x, py = y + f.row_begin, sample = 0;
+        if (f.alias > 0) {
+            px = x / f.alias; py = y / f.alias + f.row_begin;
+            sample = (y % f.alias) * f.alias + x % f.alias;
+        }
+        const double theta1 = rt355x_rotation(f.seed, px, py, sample, 0) * 2 * RT_PI; // shader.h:106-109,149-152
+        const double theta2 = rt355x_rotation(f.seed, px, py, sample, 1) * 2 * RT_PI;
+        double s1, c1, s2, c2;
+        sincos_rounded(theta1, &s1, &c1);
+        sincos_rounded(theta2, &s2, &c2);
+        const int len = ga.n;
+        uint32_t cnt = 0, sum_r = 0, sum_g = 0, sum_b = 0;
+        int i = 0;
+        for (;;) {
+            d3 ray = D3(0, 0, 0);
+            bool found = false;
+            while (i < len) {
+                const double gx = ga.dirs[3 * i], gy = ga.dirs[3 * i + 1], gz = ga.dirs[3 * i + 2];
+                i++;
+                const double x1 = c1 * gx - s1 * gy, y1 = s1 * gx + c1 * gy;              // shader.h:115,160
+                ray = D3(x1, c2 * y1 - s2 * gz, s2 * y1 + c2 * gz);                       // :119,164
+                if (!(dot(ray, h.nh) <= 0)) { found = true; break; }                      // :122,167
+            }
+            if (!found) break;
+            n_gather += 1;
+            const Ray vw = mkview(h.ph, ray);                                             // :127,173
+            Closest o;
+            o.init(1);                                                                    // t > 0, :130,176
+            int prim = 0;
+            for (; prim < s.n_prims; prim++) {
+                int is_mesh, obj;
+                const double t = prim_t(s, prim, vw, &is_mesh, &obj);
+                o.visit(prim, obj, is_mesh, t);
+                if (!BLEED && o.t_best != RT_FLT_MAX) break;                              // any hit will do, :130-133
+            }
+            n_eval += (uint32_t)min(prim + 1, s.n_prims);
+            o.commit();
+            if (BLEED) {
+                if (o.t_best < 100) {                                                     // :181-184
+                    const uint32_t hc = s.objects[s.prim_obj[o.prim_best]].rgb;
+                    sum_r += cr(hc); sum_g += cg(hc); sum_b += cb(hc);
+                    cnt += 2;
+                }
+            } else if (o.t_best != RT_FLT_MAX) {
+                cnt += 2;
+            }
+        }
+        const double part = (double)(int)cnt * 1.0 / (double)len;                         // :137,188
+        uint32_t other = sh.ambient;                                                      // cm1 of shading2, main.cpp:205
+        if (BLEED) {
+            const double n = (double)(int)cnt;                                            // :187; 0 / 0 -> colour 0
+            other = RGB(q8((double)sum_r / n), q8((double)sum_g / n), q8((double)sum_b / n));
+        }
+        clr = cadd(cmul(cm0, 1 - part), cmul(other, part));
+    }
+    store_pixel(pixmap, f, w, rid, x, y, clr);
+    } while (0);
+    wave_count(w.counters, 4, n_hit);
+    wave_count(w.counters, 1, n_eval);
+    wave_count(w.counters, 7, n_gather);
 }
 
 __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
@@ -1730,6 +1836,7 @@ struct rt355_scene {
     uint32_t work_rays = 0;
     int work_slots = 0, table_slots = 0;
     DLight *d_lights = nullptr; int lights_cap = 0;
+    double *d_dirs = nullptr; int n_dirs = 0; // direction set of the gather shaders
     // timing / stats of the outstanding render
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_search; // begin/end pairs
@@ -1756,6 +1863,14 @@ extern "C" const char *rt355_last_error(void) { return g_err.c_str(); }
 extern "C" int rt355_abi_version(void) { return RT_ABI_VERSION; }
 extern "C" double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim) {
     return rt355x_jitter(seed, x, y, sample, dim);
+}
+extern "C" double rt355_rotation(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t axis) {
+    return rt355x_rotation(seed, x, y, sample, axis);
+}
+extern "C" int rt355_sincos(double x, double *sin_out, double *cos_out) {
+    if (!sin_out || !cos_out || !(x >= 0 && x < 8)) return fail(RT355_ERR_ARG, "rt355_sincos: 0 <= x < 8");
+    sincos_rounded(x, sin_out, cos_out);
+    return RT355_OK;
 }
 
 template <typename T>
@@ -1910,6 +2025,7 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     for (void *p : sc->owned) (void)hipFree(p);
     free_tables(sc);
     if (sc->d_lights) (void)hipFree(sc->d_lights);
+    if (sc->d_dirs) (void)hipFree(sc->d_dirs);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
     for (hipEvent_t e : sc->ev_search) (void)hipEventDestroy(e);
@@ -2018,6 +2134,8 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     if (y0 < 0 || y1 > opts->height || y0 >= y1) return fail(RT355_ERR_ARG, "row slab out of range");
     if (opts->mode != RT355_MODE_ALLPAIRS && opts->mode != RT355_MODE_BRUTE && opts->mode != RT355_MODE_PACKET)
         return fail(RT355_ERR_ARG, "unknown mode");
+    if (opts->shading != RT355_SHADING_LIGHTS && opts->shading != RT355_SHADING_OCCLUSION && opts->shading != RT355_SHADING_BLEED)
+        return fail(RT355_ERR_ARG, "unknown shading");
     HIP_TRY(hipSetDevice(sc->device));
     if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     hipStream_t st = (hipStream_t)hip_stream;
@@ -2062,6 +2180,10 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     // bundle 0 = camera rays (common origin: the eye); bundle 1+k = shadow rays of light k (common
     // origin: the light position, or common direction for a directional light)
     const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
+    const bool gather = opts->shading != RT355_SHADING_LIGHTS;
+    if (can_search && gather)
+        return fail(RT355_ERR_UNSUPPORTED, "the gather shaders (shading2 / shading3, shader.h:100-191) are rendered only without a search so far: "
+                                           "scenes of fewer than 64 primitives, or RT355_MODE_BRUTE");
     if (can_search && sc->reflective)
         return fail(RT355_ERR_UNSUPPORTED, "objects with ks != 0 (reflection rays, main.cpp:93-112) are rendered only without a search so far: "
                                            "scenes of fewer than 64 primitives, or RT355_MODE_BRUTE");
@@ -2215,7 +2337,12 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     };
     if (!can_search) { // nothing to search: the whole pixel in one kernel
         HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
-        if (sc->reflective)
+        const Gather ga{sc->d_dirs, sc->n_dirs};
+        if (opts->shading == RT355_SHADING_BLEED)
+            hipLaunchKernelGGL(k_render_gather<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix);
+        else if (opts->shading == RT355_SHADING_OCCLUSION)
+            hipLaunchKernelGGL(k_render_gather<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix);
+        else if (sc->reflective)
             hipLaunchKernelGGL(k_render_direct<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
         else
             hipLaunchKernelGGL(k_render_direct<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
@@ -2272,10 +2399,10 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     HIP_TRY(hipSetDevice(sc->device));
     HIP_TRY(hipEventSynchronize(sc->ev_end));
     sc->pending = false;
-    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(shards, sc->work.counters, sizeof shards, hipMemcpyDeviceToHost));
     for (int i = 0; i < COUNTER_SHARDS; i++)
-        for (int j = 0; j < 7; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
+        for (int j = 0; j < 8; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
     sc->search_ms = 0;
@@ -2318,6 +2445,7 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         s->packet_survivors = ctr[3];
         s->primary_hits = ctr[4];
         s->secondary_rays = ctr[6];
+        s->gather_rays = ctr[7];
 #ifdef RT355_DEBUG_SURVIVORS
         { unsigned long long used = 0; for (int i = 0; i < COUNTER_SHARDS; i++) used += shards[i * COUNTER_STRIDE + 13];
           fprintf(stderr, "[rt355] shadow candidate loops: %llu lane slots for %llu candidates (%.1f %% used)\n", shards[12], used, 100.0 * (double)used / (double)std::max(1ull, shards[12])); }
@@ -2375,6 +2503,43 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     }
     (void)hipFree(d);
     return rc;
+}
+
+extern "C" int rt355_scene_set_directions(rt355_scene *sc, const double *xyz, int32_t n) {
+    if (!sc || n < 0 || (n && !xyz)) return fail(RT355_ERR_ARG, "rt355_scene_set_directions: bad argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
+    if (sc->d_dirs) { (void)hipFree(sc->d_dirs); sc->d_dirs = nullptr; }
+    sc->n_dirs = 0;
+    if (n) {
+        HIP_TRY(hipMalloc((void **)&sc->d_dirs, (size_t)n * 3 * sizeof(double)));
+        HIP_TRY(hipMemcpy(sc->d_dirs, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
+        sc->n_dirs = n;
+    }
+    return RT355_OK;
+}
+
+// Debug probe: the device's sincos_rounded for n host arguments (0 <= x < 8) -> n x 2 doubles (sin, cos)
+__global__ void k_probe_sincos(const double *__restrict__ x, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double sv, cv;
+    sincos_rounded(x[i], &sv, &cv);
+    out[2 * i] = sv; out[2 * i + 1] = cv;
+}
+extern "C" int rt355_probe_sincos(const double *x, int n, double *out) {
+    if (!x || !out || n <= 0) return fail(RT355_ERR_ARG, "rt355_probe_sincos: bad argument");
+    for (int i = 0; i < n; i++)
+        if (!(x[i] >= 0 && x[i] < 8)) return fail(RT355_ERR_ARG, "rt355_probe_sincos: 0 <= x < 8");
+    double *dx = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **)&dx, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 2 * sizeof(double)));
+    HIP_TRY(hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_sincos, dim3((n + 127) / 128), dim3(128), 0, 0, dx, n, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dout);
+    return RT355_OK;
 }
 
 // Debug probe: objs[obj]->CalcIntersect for n host rays (n x 6 doubles) -> n x 9 doubles

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rt_sincos_tables.h"
 
 #define RT_FLT_MAX 3.4028234663852886e38 /* FLT_MAX held in a double: main.cpp:45, shader.h:401 */
 #define RT_PI 3.1415927                  /* texture.h:17 (shader.h:15 and main.cpp:23 are #ifndef) */
@@ -168,18 +169,21 @@ __device__ __forceinline__ double tri_t(const DTriangle &t, const Ray &e, int *o
 // triangles the same way and reports a miss unless its minimum is > 0 (anyobject.h:646-666).
 // Primitives arrive here in scene-list order (possibly with gaps: non-candidates are misses),
 // so the per-object reduction is done on the fly and committed when the object changes.
+// The gather loops of shading2 / shading3 take an object's hit only when `t > 0` (shader.h:130,176):
+// `positive` selects that rule for the commit of an object.
 struct Closest {
     double t_best; int prim_best;
-    double t_obj; int prim_obj; int cur_obj; int cur_is_mesh;
-    __device__ __forceinline__ void init() {
+    double t_obj; int prim_obj; int cur_obj; int cur_is_mesh; int positive;
+    __device__ __forceinline__ void init(int positive_only = 0) {
         t_best = RT_FLT_MAX; prim_best = -1; t_obj = RT_FLT_MAX; prim_obj = -1; cur_obj = -1; cur_is_mesh = 0;
+        positive = positive_only;
     }
     __device__ __forceinline__ void commit() {
         if (cur_obj < 0) return;
         double tt = t_obj;
         if (cur_is_mesh) { if (!(t_obj > 0 && t_obj != RT_FLT_MAX)) tt = -1; }
         else if (t_obj == RT_FLT_MAX) tt = -1;
-        if (tt >= 0 && tt < t_best) { t_best = tt; prim_best = prim_obj; }
+        if ((positive ? tt > 0 : tt >= 0) && tt < t_best) { t_best = tt; prim_best = prim_obj; }
         cur_obj = -1;
     }
     __device__ __forceinline__ void visit(int prim, int obj, int is_mesh, double t) {
@@ -314,7 +318,7 @@ __device__ __forceinline__ uint32_t calc_diffuse(const DLight &L, uint32_t cm0, 
 // along), so the returned double is the correctly rounded power except within ~2^-50 ulp of a tie --
 // the accuracy of a correctly rounded library pow at a quarter of the instructions.
 struct dd2 { double h, l; };
-__device__ __forceinline__ dd2 dd_mul(dd2 a, dd2 b) {
+__host__ __device__ __forceinline__ dd2 dd_mul(dd2 a, dd2 b) {
     const double p = a.h * b.h;
     double e = __builtin_fma(a.h, b.h, -p);
     e = __builtin_fma(a.h, b.l, e);
@@ -328,6 +332,54 @@ __device__ __forceinline__ double pow25(double x) {
     dd2 x1; x1.h = x; x1.l = 0.0;
     const dd2 x2 = dd_mul(x1, x1), x4 = dd_mul(x2, x2), x8 = dd_mul(x4, x4), x16 = dd_mul(x8, x8);
     return dd_mul(dd_mul(x16, x8), x1).h;
+}
+// sin and cos of the gather rotation angles (shader.h:115,119,160,164), 0 <= x < 8.  The reference calls its
+// C library, whose last bit differs between libraries, and that bit shows in the frame: a gather ray that
+// starts on a sphere's surface hits or misses that sphere by the sign of a rounding error.  The path is
+// therefore defined on the correctly rounded functions, computed here as the argument minus the nearest
+// multiple of pi/2 (Cody-Waite with a 172-bit pi/2) and both Taylor series in double-double arithmetic:
+// the correctly rounded value except within ~2^-45 ulp of a tie.
+__host__ __device__ __forceinline__ dd2 dd_sum(double a, double b) { // a + b exactly
+    dd2 r;
+    r.h = a + b;
+    const double bb = r.h - a;
+    r.l = (a - (r.h - bb)) + (b - bb);
+    return r;
+}
+__host__ __device__ __forceinline__ dd2 dd_add(dd2 a, dd2 b) {
+    const dd2 s = dd_sum(a.h, b.h);
+    const double e = s.l + (a.l + b.l);
+    dd2 r;
+    r.h = s.h + e;
+    r.l = e - (r.h - s.h);
+    return r;
+}
+__host__ __device__ __forceinline__ void sincos_rounded(double x, double *sin_out, double *cos_out) {
+    const int k = (int)(x * RT_TWO_OVER_PI + 0.5);
+    const double kd = (double)k;
+    // x - k * pi/2: the first two products and the first difference are exact
+    dd2 r = dd_sum(x - kd * RT_PIO2_1, -(kd * RT_PIO2_2));
+    const double p3 = kd * RT_PIO2_3;
+    dd2 tail; tail.h = -p3; tail.l = -(__builtin_fma(kd, RT_PIO2_3, -p3) + kd * RT_PIO2_3T);
+    r = dd_add(r, tail);
+    const dd2 z = dd_mul(r, r);
+    dd2 ps; ps.h = RT_SIN_COEF[RT_SIN_TERMS - 1][0]; ps.l = RT_SIN_COEF[RT_SIN_TERMS - 1][1];
+#pragma unroll
+    for (int n = RT_SIN_TERMS - 2; n >= 0; n--) {
+        dd2 c; c.h = RT_SIN_COEF[n][0]; c.l = RT_SIN_COEF[n][1];
+        ps = dd_add(dd_mul(ps, z), c);
+    }
+    ps = dd_mul(ps, r);
+    dd2 pc; pc.h = RT_COS_COEF[RT_COS_TERMS - 1][0]; pc.l = RT_COS_COEF[RT_COS_TERMS - 1][1];
+#pragma unroll
+    for (int n = RT_COS_TERMS - 2; n >= 0; n--) {
+        dd2 c; c.h = RT_COS_COEF[n][0]; c.l = RT_COS_COEF[n][1];
+        pc = dd_add(dd_mul(pc, z), c);
+    }
+    const int q = k & 3;
+    const double sv = (q & 1) ? pc.h : ps.h, cv = (q & 1) ? ps.h : pc.h;
+    *sin_out = (q & 2) ? -sv : sv;
+    *cos_out = (q == 1 || q == 2) ? -cv : cv;
 }
 // reh of CalcSpecular (shader.h:352): the view direction mirrored at the surface; the same for every light
 __device__ __forceinline__ d3 mirror_dir(d3 nh, d3 npe) {

@@ -18,19 +18,23 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in rt355.h but not exported"
     L.rt355_abi_version.restype = ctypes.c_int
-    assert L.rt355_abi_version() >= 2
+    assert L.rt355_abi_version() >= 3
     # the exported jitter and its Python mirror
     from raytracer_amd import binding as B
     L.rt355_jitter.restype = ctypes.c_double
     L.rt355_jitter.argtypes = [ctypes.c_uint32] + [ctypes.c_int32] * 4
     for a in ((0, 0, 0, 0, 0), (5, 17, 3, 8, 1), (4_000_000_000, 3839, 2159, 15, 0)):
         assert L.rt355_jitter(*a) == B.jitter(*a)
+    L.rt355_rotation.restype = ctypes.c_double
+    L.rt355_rotation.argtypes = [ctypes.c_uint32] + [ctypes.c_int32] * 4
+    for a in ((0, 0, 0, 0, 0), (5, 17, 3, 8, 1), (4_000_000_000, 3839, 2159, 15, 0)):
+        assert L.rt355_rotation(*a) == B.rotation(*a)
 
 
 def test_struct_sizes_match_header_layout():
     from raytracer_amd import binding as B
     assert B.OBJECT_DTYPE.itemsize == 184 and B.LIGHT_DTYPE.itemsize == 80
-    assert ctypes.sizeof(B.CCamera) == 96 and ctypes.sizeof(B.CStats) == 72
+    assert ctypes.sizeof(B.CCamera) == 96 and ctypes.sizeof(B.CStats) == 80
 
 
 def test_null_arguments_are_rejected_without_a_gpu():

@@ -354,3 +354,75 @@ def test_random_scenes_search_is_conservative(api, oracle, seed):
     _compare(packet, want)
     assert st["shadow_rays"] == wst["shadow_rays"]
     assert pst["exact_tests"] == st["exact_tests"]
+
+
+@pytest.mark.gpu
+def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
+    """CalcSubPixel2 with shading3 / shading2 (main.cpp:163-209, shader.h:100-191), HEAD's renderer: frames
+    the reference's own shader code produced (fixtures), then more cases against the CPU checker, ray counts
+    included.  Both sides take the two random numbers per hit from rt355_rotation."""
+    import json, os
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    for c in meta["gather_cases"]:
+        sc, sh, cam, w, h = S.small_case(c["case"])
+        w, h = c["width"], c["height"]
+        cam = S.default_camera(w, h)
+        r = api.Renderer(sc)
+        r.set_directions(B.geodesic(B.icosphere(c["level"])))
+        got, st = r.render(cam, sh, w, h, alias=c["alias"], seed=c["seed"], shading=c["shading"], mode=B.MODE_BRUTE)
+        r.close()
+        _compare(got, np.load(os.path.join(golden_dir, c["file"])))
+        assert st["gather_rays"] > 0 and st["shadow_rays"] == 0
+    for name in ("default_2lights", "inside", "mesh", "spheres300", "empty_scene"):
+        sc, sh, cam, w, h = S.small_case(name)
+        w, h = (w // 2) | 1, (h // 2) | 1
+        cam = S.default_camera(w, h)
+        r = api.Renderer(sc)
+        for level, shading, alias in ((2, B.SHADING_BLEED, 0), (1, B.SHADING_OCCLUSION, 0), (0, B.SHADING_BLEED, 3)):
+            dirs = B.geodesic(B.icosphere(level))
+            r.set_directions(dirs)
+            want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=9, shading=shading), threads=0, dirs=dirs)
+            got, st = r.render(cam, sh, w, h, alias=alias, seed=9, shading=shading, mode=B.MODE_BRUTE)
+            _compare(got, want)
+            assert st["gather_rays"] == wst["gather_rays"], (name, level, shading, alias)
+        r.close()
+
+
+@pytest.mark.gpu
+def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle):
+    """A scene of a few objects renders the gather shaders in every mode (nothing is searched), slab by slab
+    as well; no direction set gives black hits; a searched scene is refused with a message that says why."""
+    sc, sh, cam, w, h = S.small_case("default_2lights")
+    dirs = B.geodesic(B.icosphere(1))
+    want, _ = oracle.render(sc.pack(), cam, sh, B.opts(w, h, seed=3, shading=B.SHADING_BLEED), threads=0, dirs=dirs)
+    r = api.Renderer(sc)
+    black, st = r.render(cam, sh, w, h, seed=3, shading=B.SHADING_BLEED)
+    assert not black.any() and st["gather_rays"] == 0 and st["primary_hits"] > 0
+    r.set_directions(dirs)
+    for mode in (B.MODE_PACKET, B.MODE_ALLPAIRS, B.MODE_BRUTE):
+        got, _ = r.render(cam, sh, w, h, seed=3, shading=B.SHADING_BLEED, mode=mode)
+        _compare(got, want)
+    parts = np.zeros_like(want)
+    for y0, y1 in ((0, 11), (11, h)):
+        r.render(cam, sh, w, h, row_begin=y0, row_end=y1, out=parts, seed=3, shading=B.SHADING_BLEED)
+    assert np.array_equal(parts, want)
+    r.close()
+    big, bsh, bcam, bw, bh = S.small_case("spheres300")
+    r = api.Renderer(big)
+    r.set_directions(dirs)
+    with pytest.raises(api.Rt355Error, match="gather"):
+        r.render(bcam, bsh, bw, bh, shading=B.SHADING_BLEED, mode=B.MODE_PACKET)
+    r.close()
+
+
+@pytest.mark.gpu
+def test_device_sincos_equals_host_evaluation(api):
+    """The rotation's sine and cosine on the device are the doubles rt355_sincos returns on the host (which
+    tests/test_host_math.py checks against exact arithmetic)."""
+    import math
+    rng = np.random.default_rng(357)
+    xs = np.concatenate([rng.random(20000) * 2 * 3.1415927, [k * math.pi / 2 for k in range(5)],
+                         [math.nextafter(k * math.pi / 2, 9.0) for k in range(5)], [0.0, 1e-300, 1e-9, 2 * 3.1415927]])
+    dev = api.probe_sincos(xs)
+    host = np.array([api.sincos(float(x)) for x in xs])
+    assert np.array_equal(dev, host)

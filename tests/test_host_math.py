@@ -1,6 +1,7 @@
 """Arithmetic identities the device code relies on, checked on the CPU against the reference's
 double-precision Color semantics (color.h:25-45: truncate toward zero, keep the low byte)."""
 import numpy as np
+import pytest
 
 
 def q8(x):
@@ -65,3 +66,43 @@ def test_power_25_in_double_double_is_correctly_rounded():
     for c in (255.0, 221.0, 200.0, 100.0, 16.0, 1.0):
         assert np.array_equal(q8(c * chain), q8(c * ref))
         assert np.array_equal(q8(c * (1 - chain)), q8(c * (1 - ref)))
+
+
+def _exact_sincos(x):
+    """sin and cos of a double from their Taylor series in rational arithmetic, rounded once."""
+    from fractions import Fraction
+    X = Fraction(x)
+    sv = cv = Fraction(0)
+    term, n = Fraction(1), 0
+    while n < 30 or abs(term) > Fraction(1, 1 << 260):
+        if n % 2 == 0:
+            cv += term if (n // 2) % 2 == 0 else -term
+        else:
+            sv += term if (n // 2) % 2 == 0 else -term
+        n += 1
+        term = term * X / n
+    return float(sv), float(cv)
+
+
+def test_rotation_sine_and_cosine_are_correctly_rounded(oracle):
+    """shading2 / shading3 rotate the direction set with the C library's sin and cos (shader.h:115,119), whose
+    last bit differs between libraries; the gather path is defined on the correctly rounded functions.  The
+    device evaluates them in double-double arithmetic, and rt355_sincos is that same code compiled for the
+    host: against exact rational arithmetic every result is the correctly rounded one, it equals the
+    checker's (binary128, rounded once), and the C library of this host differs in the last bit now and
+    then."""
+    import math
+    from raytracer_amd import api
+    rng = np.random.default_rng(356)
+    xs = list(rng.random(1500) * 2 * 3.1415927)
+    xs += [k * math.pi / 2 for k in range(5)] + [math.nextafter(k * math.pi / 2, 9.0) for k in range(5)]
+    xs += [math.nextafter(k * math.pi / 2, 0.0) for k in range(1, 5)] + [0.0, 1e-300, 1e-9, 2 * 3.1415927]
+    off = 0
+    for x in xs:
+        got = api.sincos(float(x))
+        assert got == _exact_sincos(float(x)), x
+        assert got == oracle.sincos(float(x), rounded=True), x
+        off += got != oracle.sincos(float(x))
+    assert off <= len(xs) // 50
+    with pytest.raises(api.Rt355Error):
+        api.sincos(8.5)
