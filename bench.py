@@ -387,7 +387,8 @@ def main():
         for name in OTHERS:
             others[name] = measure(name, args, ctx, headline=False)
     if rank == 0:
-        out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160",  # gather rays counted too where a workload casts them "value": head["value"], "unit": "Mrays/s",
+        # (a workload that casts gather rays counts them too)
+        out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
                "higher_is_better": True, "scaling": "weak" if (args.shard == "frames" or world == 1) else "strong",
                "vs_baseline": None, "dtype": "f64" if head["kernel_time"]["search_ms_per_frame"] == 0 else "f32 search + f64 resolve",

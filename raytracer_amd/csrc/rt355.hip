@@ -1252,12 +1252,7 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
     }
     if (brute) {
         c.init();
-        for (int prim = 0; prim < s.n_prims; prim++) {
-            int is_mesh, obj;
-            double t = prim_t(s, prim, e, &is_mesh, &obj);
-            c.visit(prim, obj, is_mesh, t);
-        }
-        c.commit();
+        closest_by_kind<false, false>(s, e, c.t_best, c.prim_best);
         n = (uint32_t)s.n_prims;
     }
     evaluated += n;
@@ -1542,11 +1537,15 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
 // (about z, then about x), skip the directions with ray . nh <= 0 and cast the others from the hit point
 // against every object, taking hits with t > 0 only.  cm0 is the object's own colour as CalcIntersect
 // returns it: no texture lookup, lights, border or reflection on this path.  The angles come from
-// rt355x_rotation in place of rand().  A lane looks for its next direction that passes the normal test
-// before the wave walks the primitives together, so the lanes skipped by that test do not idle through
-// a walk.
+// rt355x_rotation in place of rand(), their sine and cosine from sincos_rounded.
 struct Gather { const double *dirs; int32_t n; };
-template <bool BLEED>
+// FEW > 0: the scene has at most FEW planes, at most FEW spheres and no mesh (the reference's own scene is
+// two planes and two spheres).  All gather rays of a hit share their origin, so the terms of
+// Plane::CalcIntersect and Sphere::CalcIntersect that depend on the origin alone -- ni . (pe - pi), pe - c,
+// |pe - c|^2 - r^2 and the inside / outside decision -- are evaluated once per hit and kept in registers,
+// and the loops over the objects unroll; the values are the ones the reference recomputes for every ray.
+#define GATHER_FEW 4
+template <bool BLEED, int FEW>
 __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                        Gather ga, unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1576,41 +1575,112 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
         double s1, c1, s2, c2;
         sincos_rounded(theta1, &s1, &c1);
         sincos_rounded(theta2, &s2, &c2);
+        // origin terms of the few objects (see above); index 0 of the arrays exists even when FEW == 0
+        constexpr int NF = FEW > 0 ? FEW : 1;
+        d3 plane_n[NF], sphere_cpe[NF];
+        double plane_num[NF], sphere_cc[NF], sphere_out[NF];
+        int plane_prim[NF], sphere_prim[NF];
+        if (FEW > 0) {
+#pragma unroll
+            for (int k = 0; k < NF; k++) {
+                plane_prim[k] = -1; plane_n[k] = D3(0, 0, 0); plane_num[k] = 0;
+                if (k < s.n_planes) {
+                    plane_prim[k] = s.kind_prims[k];
+                    const DObject &o = s.objects[s.prim_obj[plane_prim[k]]];
+                    plane_n[k] = ld3(o.n);
+                    plane_num[k] = -dot(plane_n[k], vsub(h.ph, ld3(o.p)));                // anyobject.h:84
+                }
+                sphere_prim[k] = -1; sphere_cpe[k] = D3(0, 0, 0); sphere_cc[k] = 0; sphere_out[k] = 1;
+                if (k < s.n_spheres) {
+                    sphere_prim[k] = s.kind_prims[s.n_planes + k];
+                    const double4 q = s.prim_rec[sphere_prim[k]];
+                    const d3 ctr = D3(q.x, q.y, q.z);
+                    const d3 ec = vsub(h.ph, ctr);
+                    sphere_cc[k] = dot(ec, ec) - q.w * q.w;                               // anyobject.h:137,146
+                    sphere_out[k] = (sphere_cc[k] <= -0.00001) ? -1.0 : 1.0;
+                    sphere_cpe[k] = vsub(ctr, h.ph);
+                }
+            }
+        }
         const int len = ga.n;
         uint32_t cnt = 0, sum_r = 0, sum_g = 0, sum_b = 0;
-        int i = 0;
-        for (;;) {
-            d3 ray = D3(0, 0, 0);
-            bool found = false;
-            while (i < len) {
-                const double gx = ga.dirs[3 * i], gy = ga.dirs[3 * i + 1], gz = ga.dirs[3 * i + 2];
-                i++;
-                const double x1 = c1 * gx - s1 * gy, y1 = s1 * gx + c1 * gy;              // shader.h:115,160
-                ray = D3(x1, c2 * y1 - s2 * gz, s2 * y1 + c2 * gz);                       // :119,164
-                if (!(dot(ray, h.nh) <= 0)) { found = true; break; }                      // :122,167
+        // The normal test ray . nh <= 0 (shader.h:122,167) drops about half of the directions, a different
+        // half in every lane.  So the directions are taken 128 at a time: first every lane marks the ones
+        // that may pass -- g . m with m = the normal turned back by the two rotations is ray . nh up to
+        // rounding, so anything above -eps is marked -- then the lanes work through their own marks together,
+        // and the reference's own test on the reference's own rotated ray decides.  The order in which a
+        // lane meets its directions does not matter: the results are counts and sums of 8-bit colours.
+        const double rot_a = h.nh.y * c2 + h.nh.z * s2;
+        const double mx = h.nh.x * c1 + rot_a * s1, my = rot_a * c1 - h.nh.x * s1, mz = h.nh.z * c2 - h.nh.y * s2;
+        const double eps = 1e-13 * (fabs(h.nh.x) + fabs(h.nh.y) + fabs(h.nh.z));
+        for (int base = 0; base < len; base += 128) { // uniform
+            const int n_low = min(64, len - base), n_high = min(128, len - base) - 64;
+            unsigned long long marks0 = 0ull, marks1 = 0ull;
+            for (int j = 0; j < n_low; j++) {
+                const double *g = ga.dirs + 3 * (size_t)(base + j);
+                const double d = __builtin_fma(g[0], mx, __builtin_fma(g[1], my, g[2] * mz));
+                marks0 |= (unsigned long long)(!(d <= -eps)) << j;
             }
-            if (!found) break;
-            n_gather += 1;
-            const Ray vw = mkview(h.ph, ray);                                             // :127,173
-            Closest o;
-            o.init(1);                                                                    // t > 0, :130,176
-            int prim = 0;
-            for (; prim < s.n_prims; prim++) {
-                int is_mesh, obj;
-                const double t = prim_t(s, prim, vw, &is_mesh, &obj);
-                o.visit(prim, obj, is_mesh, t);
-                if (!BLEED && o.t_best != RT_FLT_MAX) break;                              // any hit will do, :130-133
+            for (int j = 0; j < n_high; j++) {
+                const double *g = ga.dirs + 3 * (size_t)(base + 64 + j);
+                const double d = __builtin_fma(g[0], mx, __builtin_fma(g[1], my, g[2] * mz));
+                marks1 |= (unsigned long long)(!(d <= -eps)) << j;
             }
-            n_eval += (uint32_t)min(prim + 1, s.n_prims);
-            o.commit();
-            if (BLEED) {
-                if (o.t_best < 100) {                                                     // :181-184
-                    const uint32_t hc = s.objects[s.prim_obj[o.prim_best]].rgb;
-                    sum_r += cr(hc); sum_g += cg(hc); sum_b += cb(hc);
-                    cnt += 2;
+            auto pop = [&]() -> int { // this lane's next marked direction, -1 when it has none left
+                if (marks0) { const int b = __ffsll((long long)marks0) - 1; marks0 &= marks0 - 1; return base + b; }
+                if (marks1) { const int b = __ffsll((long long)marks1) - 1; marks1 &= marks1 - 1; return base + 64 + b; }
+                return -1;
+            };
+            auto fetch = [&](int i) -> d3 {
+                if (i < 0) return D3(0, 0, 0);
+                const double *g = ga.dirs + 3 * (size_t)i;
+                return D3(g[0], g[1], g[2]);
+            };
+            int i = pop();
+            d3 g = fetch(i);
+            while (i >= 0) {
+                const int i_next = pop();       // its direction is on the way while this one is worked on
+                const d3 g_next = fetch(i_next);
+                const double x1 = c1 * g.x - s1 * g.y, y1 = s1 * g.x + c1 * g.y;          // shader.h:115,160
+                const d3 ray = D3(x1, c2 * y1 - s2 * g.z, s2 * y1 + c2 * g.z);            // :119,164
+                if (!(dot(ray, h.nh) <= 0)) {                                             // :122,167
+                    n_gather += 1;
+                    const Ray vw = mkview(h.ph, ray);                                     // :127,173
+                    double t_hit = RT_FLT_MAX; int prim_hit = -1;                         // t > 0, :130,176
+                    if (FEW > 0) {
+                        auto consider = [&](double t, int prim) {
+                            if (t > 0 && (t < t_hit || (t == t_hit && prim < prim_hit))) { t_hit = t; prim_hit = prim; }
+                        };
+#pragma unroll
+                        for (int k = 0; k < NF; k++) {
+                            if (k < s.n_planes) {                                         // anyobject.h:79-84
+                                const double dn = dot(plane_n[k], vw.npe);
+                                consider((dn >= 0) ? -1.0 : plane_num[k] / dn, plane_prim[k]);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < NF; k++) {
+                            if (k < s.n_spheres) {                                        // anyobject.h:144-154
+                                const double B = dot(vw.npe, sphere_cpe[k]);
+                                const double delta = B * B - sphere_cc[k];
+                                consider((delta < 0) ? -1.0 : B - sphere_out[k] * sqrt(delta), sphere_prim[k]);
+                            }
+                        }
+                    } else {
+                        closest_by_kind<true, !BLEED>(s, vw, t_hit, prim_hit);            // shading2: any hit will do, :130-133
+                    }
+                    n_eval += (uint32_t)s.n_prims;
+                    if (BLEED) {
+                        if (t_hit < 100) {                                                // :181-184
+                            const uint32_t hc = s.objects[s.prim_obj[prim_hit]].rgb;
+                            sum_r += cr(hc); sum_g += cg(hc); sum_b += cb(hc);
+                            cnt += 2;
+                        }
+                    } else if (prim_hit >= 0) {
+                        cnt += 2;
+                    }
                 }
-            } else if (o.t_best != RT_FLT_MAX) {
-                cnt += 2;
+                i = i_next; g = g_next;
             }
         }
         const double part = (double)(int)cnt * 1.0 / (double)len;                         // :137,188
@@ -1891,7 +1961,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         return fail(RT355_ERR_ARG, "rt355_scene_create: inconsistent counts/pointers");
     std::vector<DObject> objs(d->n_objects);
     std::vector<DTriangle> tris(d->n_triangles);
-    std::vector<int32_t> prim_obj, prim_tri;
+    std::vector<int32_t> prim_obj, prim_tri, by_kind[3];
     std::vector<double4> prim_rec;
     bool any_ks = false;
     double rmax = 0, extent = 0;
@@ -1924,10 +1994,12 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
             if (o.tri_begin < 0 || o.tri_count < 0 || (int64_t)o.tri_begin + o.tri_count > d->n_triangles)
                 return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": triangle range out of bounds");
             for (int k = 0; k < o.tri_count; k++) {
+                by_kind[2].push_back((int32_t)prim_obj.size());
                 prim_obj.push_back(i); prim_tri.push_back(o.tri_begin + k);
                 prim_rec.push_back(index_rec(i, o.tri_begin + k));
             }
         } else {
+            by_kind[o.type == RT355_OBJ_SPHERE ? 1 : 0].push_back((int32_t)prim_obj.size());
             prim_obj.push_back(i); prim_tri.push_back(-1);
             prim_rec.push_back(o.type == RT355_OBJ_SPHERE ? make_double4(o.p[0], o.p[1], o.p[2], o.radius) : index_rec(i, -1));
         }
@@ -1958,10 +2030,13 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         tex[i].offset = pool.size(); tex[i].sx = t.sx; tex[i].sy = t.sy; tex[i].width = t.width; tex[i].height = t.height;
         pool.insert(pool.end(), t.rgb, t.rgb + (size_t)t.width * t.height * 3);
     }
+    std::vector<int32_t> kind_prims(by_kind[0]);
+    kind_prims.insert(kind_prims.end(), by_kind[1].begin(), by_kind[1].end());
+    kind_prims.insert(kind_prims.end(), by_kind[2].begin(), by_kind[2].end());
     rt355_scene *sc = new rt355_scene();
     HIP_TRY(hipGetDevice(&sc->device));
     int rc;
-    if ((rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
+    if ((rc = upload(sc, kind_prims, &sc->view.kind_prims)) || (rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
         (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
         (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || 
         (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels))) {
@@ -1970,6 +2045,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     }
     sc->view.n_objects = d->n_objects;
     sc->view.n_prims = (int)prim_obj.size();
+    sc->view.n_planes = (int)by_kind[0].size(); sc->view.n_spheres = (int)by_kind[1].size();
     sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
     if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
     if (const char *e = getenv("RT355_PACKET_RAYS")) {
@@ -2338,10 +2414,16 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     if (!can_search) { // nothing to search: the whole pixel in one kernel
         HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
         const Gather ga{sc->d_dirs, sc->n_dirs};
-        if (opts->shading == RT355_SHADING_BLEED)
-            hipLaunchKernelGGL(k_render_gather<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix);
-        else if (opts->shading == RT355_SHADING_OCCLUSION)
-            hipLaunchKernelGGL(k_render_gather<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix);
+        const SceneView &v = sc->view;
+        const bool few = v.n_planes <= GATHER_FEW && v.n_spheres <= GATHER_FEW && v.n_planes + v.n_spheres == v.n_prims &&
+                         !getenv("RT355_GATHER_GENERAL");
+#define LAUNCH_GATHER(B, F) hipLaunchKernelGGL((k_render_gather<B, F>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix)
+        if (opts->shading == RT355_SHADING_BLEED) {
+            if (few) LAUNCH_GATHER(true, GATHER_FEW); else LAUNCH_GATHER(true, 0);
+        } else if (opts->shading == RT355_SHADING_OCCLUSION) {
+            if (few) LAUNCH_GATHER(false, GATHER_FEW); else LAUNCH_GATHER(false, 0);
+        }
+#undef LAUNCH_GATHER
         else if (sc->reflective)
             hipLaunchKernelGGL(k_render_direct<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
         else

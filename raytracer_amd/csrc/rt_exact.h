@@ -201,7 +201,9 @@ struct SceneView { // device pointers of an uploaded scene
                                // radius; for a triangle or plane the first 8 bytes hold (object, triangle)
     const DTexture *textures;
     const uint8_t *texels;
-    int32_t n_objects, n_prims;
+    const int32_t *kind_prims; // the primitives sorted by kind: n_planes planes, n_spheres spheres, then the
+                               // triangles of all meshes, each kind in scene-list order
+    int32_t n_objects, n_prims, n_planes, n_spheres;
 };
 
 __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray &e, int *is_mesh, int *obj_out) {
@@ -218,6 +220,47 @@ __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray
     if (o.type == RT_OBJ_PLANE) return plane_t(o, e);
     int outside;
     return sphere_t(o, e, &outside);
+}
+
+// The closest hit over ALL primitives, one loop per kind of primitive instead of a dispatch per primitive.
+// The ordered rule above is restated without order as the smallest (t, primitive) pair: objects are
+// numbered in list order, so on equal t the smaller primitive index is the earlier object.  Planes and
+// spheres are objects of their own; the triangles arrive in list order and go through Closest, which keeps
+// the mesh rules.  POSITIVE: hits need t > 0 (gather rays, shader.h:130,176), else t >= 0.  ANY: stop at
+// the first hit found, whichever it is (shading2 only asks whether there is one, shader.h:130-133).
+template <bool POSITIVE, bool ANY>
+__device__ __forceinline__ void closest_by_kind(const SceneView &s, const Ray &e, double &t_best, int &prim_best) {
+    double bt = RT_FLT_MAX;
+    int bprim = -1;
+    auto consider = [&](double t, int prim) {
+        if ((POSITIVE ? t > 0 : t >= 0) && (t < bt || (t == bt && prim < bprim))) { bt = t; bprim = prim; }
+    };
+    int k = 0;
+    for (; k < s.n_planes; k++) {
+        const int prim = s.kind_prims[k];
+        consider(plane_t(s.objects[s.prim_obj[prim]], e), prim);
+        if (ANY && bprim >= 0) break;
+    }
+    if (!(ANY && bprim >= 0))
+        for (k = s.n_planes; k < s.n_planes + s.n_spheres; k++) {
+            const int prim = s.kind_prims[k];
+            consider(sphere_t_rec(s.prim_rec[prim], e), prim);
+            if (ANY && bprim >= 0) break;
+        }
+    if (!(ANY && bprim >= 0) && s.n_planes + s.n_spheres < s.n_prims) {
+        Closest c;
+        c.init(POSITIVE ? 1 : 0);
+        for (k = s.n_planes + s.n_spheres; k < s.n_prims; k++) {
+            const int prim = s.kind_prims[k];
+            int outside; d3 ph; double u, v;
+            const double t = tri_t(s.tris[s.prim_tri[prim]], e, &outside, &ph, &u, &v);
+            c.visit(prim, s.prim_obj[prim], 1, t);
+            if (ANY && c.t_best != RT_FLT_MAX) break;
+        }
+        c.commit();
+        if (c.prim_best >= 0) consider(c.t_best, c.prim_best);
+    }
+    t_best = bt; prim_best = bprim;
 }
 
 // ---- texture.h ----------------------------------------------------------------------------------

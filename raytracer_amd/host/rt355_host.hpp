@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -157,14 +159,50 @@ public:
     DeviceScene(const DeviceScene &) = delete;
     DeviceScene &operator=(const DeviceScene &) = delete;
     rt355_scene *handle() const { return h_; }
+    // the global `geo` of main.cpp:557: the direction set of the gather shaders (shading2 / shading3)
+    void set_directions(const std::vector<Vector3D> &geo) {
+        std::vector<double> xyz;
+        for (const Vector3D &g : geo) { xyz.push_back(g.x); xyz.push_back(g.y); xyz.push_back(g.z); }
+        detail::check(rt355_scene_set_directions(h_, xyz.data(), (int32_t)geo.size()), "rt355_scene_set_directions");
+    }
 private:
     rt355_scene *h_ = nullptr;
 };
 
+// Geodesic(string filePath) of main.cpp:408-450: the `v x y z` lines of an OBJ file, minus their mean,
+// normalised.  A file that cannot be opened gives an empty set, as there (every hit then renders black).
+inline std::vector<Vector3D> Geodesic(const std::string &filePath) {
+    std::vector<Vector3D> geo;
+    std::ifstream ifs(filePath.c_str());
+    if (ifs.fail()) return geo;
+    std::string line;
+    Vector3D sum(0, 0, 0);
+    int cnt = 0;
+    while (ifs.peek() != EOF) {
+        std::getline(ifs, line);
+        if (line.substr(0, 2) != "v ") continue;
+        std::istringstream v(line.substr(2));
+        double x = 0, y = 0, z = 0;
+        v >> x; v >> y; v >> z;
+        geo.push_back(Vector3D(x, y, z));
+        sum = Vector3D(sum.x + x, sum.y + y, sum.z + z);
+        cnt++;
+    }
+    sum = Vector3D(sum.x / cnt, sum.y / cnt, sum.z / cnt);
+    for (Vector3D &g : geo) {
+        Vector3D d(0 - sum.x, 0 - sum.y, 0 - sum.z); // Point3D(0, 0, 0) - sum, main.cpp:446
+        g = Normalize(Vector3D(g.x + d.x, g.y + d.y, g.z + d.z));
+    }
+    return geo;
+}
+
 // setPixels(Scene sce, Shader shd, int alias) of main.cpp:339-376; width, height and pixmap are
-// globals there (main.cpp:33-34) and arguments here.  Returns the ray statistics.
+// globals there (main.cpp:33-34) and arguments here.  `shading` picks the renderer: RT355_SHADING_LIGHTS is
+// CalcSubPixel with Shader::shading, RT355_SHADING_BLEED what HEAD of the reference calls (CalcSubPixel2 with
+// shading3, main.cpp:313,331), on the directions given to DeviceScene::set_directions.  Returns the ray statistics.
 inline rt355_stats setPixels(DeviceScene &dev, const Scene &sce, const Shader &shd, int alias, int width, int height,
-                             unsigned char *pixmap, int row_begin = 0, int row_end = 0) {
+                             unsigned char *pixmap, int row_begin = 0, int row_end = 0,
+                             int shading = RT355_SHADING_LIGHTS, uint32_t seed = 0) {
     rt355_camera c;
     detail::put(c.v_up, sce.v_up); detail::put(c.v_view, sce.v_view); detail::put(c.p_eye, sce.p_eye);
     c.dist = sce.dist; c.s_x = sce.s_x; c.s_y = sce.s_y;
@@ -181,7 +219,7 @@ inline rt355_stats setPixels(DeviceScene &dev, const Scene &sce, const Shader &s
     detail::put(s.border, shd.border_color);
     rt355_opts o; std::memset(&o, 0, sizeof o);
     o.width = width; o.height = height; o.alias = alias; o.row_begin = row_begin; o.row_end = row_end;
-    o.mode = RT355_MODE_PACKET;
+    o.mode = RT355_MODE_PACKET; o.shading = shading; o.seed = seed;
     rt355_stats st; std::memset(&st, 0, sizeof st);
     detail::check(rt355_render(dev.handle(), &c, &s, &o, pixmap, &st), "rt355_render");
     return st;

@@ -1,8 +1,10 @@
 // rt355_main.cpp -- the reference's main() (image_synthesis/main.cpp:522-642) on the GPU path:
 // same camera, the four objects it pushes, the directional light it constructs (plus, with
 // `2` as third argument, the point light at light_src2's position), Shader colours of
-// main.cpp:630, alias 0; writes a BMP and a raw RGB8 dump.
-//   rt355_demo [width height [n_lights [out_prefix]]]
+// main.cpp:630, alias 0; writes a BMP and a raw RGB8 dump.  With a fifth argument, the path of the OBJ file
+// whose vertices are the gather directions (main.cpp:557 reads "geodesic.obj"), the frame is rendered the
+// way HEAD of the reference does: CalcSubPixel2 with Shader::shading3 (main.cpp:205,331).
+//   rt355_demo [width height [n_lights [out_prefix [geodesic.obj]]]]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -36,14 +38,18 @@ int main(int argc, char **argv) {
     Shader shd(light, Color(0x000000u), Color(0xddddddu), Color(0x000000u));
     try {
         DeviceScene dev(sce.objs);
+        const bool gather = argc > 5;
+        if (gather) dev.set_directions(Geodesic(argv[5]));
         auto t0 = std::chrono::steady_clock::now();
-        rt355_stats st = setPixels(dev, sce, shd, alias, width, height, pixmap.data());
+        rt355_stats st = setPixels(dev, sce, shd, alias, width, height, pixmap.data(), 0, 0,
+                                   gather ? RT355_SHADING_BLEED : RT355_SHADING_LIGHTS);
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         SaveImage((prefix + ".bmp").c_str(), width, height, pixmap.data());
         FILE *f = std::fopen((prefix + ".rgb").c_str(), "wb");
         if (f) { std::fwrite(pixmap.data(), 1, pixmap.size(), f); std::fclose(f); }
-        std::printf("%dx%d: %llu primary + %llu shadow rays, %.3f ms (device %.3f ms) -> %s.bmp\n", width, height,
-                    (unsigned long long)st.primary_rays, (unsigned long long)st.shadow_rays, ms, st.ms_device, prefix.c_str());
+        std::printf("%dx%d: %llu primary + %llu shadow + %llu gather rays, %.3f ms (device %.3f ms) -> %s.bmp\n", width, height,
+                    (unsigned long long)st.primary_rays, (unsigned long long)st.shadow_rays,
+                    (unsigned long long)st.gather_rays, ms, st.ms_device, prefix.c_str());
     } catch (const Error &e) {
         std::fprintf(stderr, "rt355: %s\n", e.what());
         return 1;

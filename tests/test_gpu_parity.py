@@ -305,6 +305,17 @@ def test_cpp_host_demo_matches_checker(api, oracle, tmp_path):
     assert bmp[:2] == b"BM" and len(bmp) == 54 + 320 * 240 * 3
     # BMP rows are bottom-up B,G,R: first pixel of the file = pixel (0,0) of the pixmap
     assert list(bmp[54:57]) == list(want[0, 0][::-1])
+    # HEAD's renderer: gather directions read from an OBJ file by the host's Geodesic() (main.cpp:408-450)
+    verts = [(1.5 * x + 0.25, 1.5 * y - 0.5, 1.5 * z + 1.0) for x, y, z in B.icosphere(1)]  # off-centre, not unit
+    obj = tmp_path / "geodesic.obj"
+    obj.write_text("# directions\n" + "".join(f"v {x!r} {y!r} {z!r}\n" for x, y, z in verts) + "f 1 2 3\n")
+    subprocess.run([exe, "160", "120", "1", prefix + "_g", str(obj)], check=True, timeout=100)
+    got = np.fromfile(prefix + "_g.rgb", dtype=np.uint8).reshape(120, 160, 3)
+    dirs = B.read_geodesic(str(obj))
+    assert dirs.shape == (42, 3) and np.array_equal(dirs, B.geodesic(verts))
+    want, _ = oracle.render(S.default_scene().pack(), S.default_camera(160, 120), S.default_shader(1),
+                            B.opts(160, 120, shading=B.SHADING_BLEED), threads=0, dirs=dirs)
+    _compare(got, want)
 
 
 def _random_case(seed):
@@ -389,7 +400,7 @@ def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
 
 
 @pytest.mark.gpu
-def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle):
+def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle, monkeypatch):
     """A scene of a few objects renders the gather shaders in every mode (nothing is searched), slab by slab
     as well; no direction set gives black hits; a searched scene is refused with a message that says why."""
     sc, sh, cam, w, h = S.small_case("default_2lights")
@@ -406,6 +417,16 @@ def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle):
     for y0, y1 in ((0, 11), (11, h)):
         r.render(cam, sh, w, h, row_begin=y0, row_end=y1, out=parts, seed=3, shading=B.SHADING_BLEED)
     assert np.array_equal(parts, want)
+    # a scene of at most four planes and four spheres takes the kernel that keeps the objects' origin terms in
+    # registers; the general kernel gives the same frame
+    monkeypatch.setenv("RT355_GATHER_GENERAL", "1")
+    for shading in (B.SHADING_BLEED, B.SHADING_OCCLUSION):
+        general, gst = r.render(cam, sh, w, h, seed=3, shading=shading)
+        monkeypatch.delenv("RT355_GATHER_GENERAL")
+        few, fst = r.render(cam, sh, w, h, seed=3, shading=shading)
+        monkeypatch.setenv("RT355_GATHER_GENERAL", "1")
+        assert np.array_equal(general, few) and gst["gather_rays"] == fst["gather_rays"]
+    monkeypatch.delenv("RT355_GATHER_GENERAL")
     r.close()
     big, bsh, bcam, bw, bh = S.small_case("spheres300")
     r = api.Renderer(big)
