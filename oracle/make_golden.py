@@ -67,6 +67,35 @@ def main():
         np.save(os.path.join(OUT, fn), frame)
         meta["gather_cases"].append({"case": name, "level": level, "shading": shading, "alias": alias, "seed": seed,
                                      "width": w, "height": h, "file": fn, "fnv1a64": f"{B.fnv1a64(frame):016x}"})
+    # 1d. host file formats: small OBJ and BMP files and what the reference's own readers (Mesh::Mesh,
+    #     Texture::Texture) make of them
+    ldir = os.path.join(OUT, "loaders")
+    os.makedirs(ldir, exist_ok=True)
+    objs = {
+        "plain.obj": "# three numbers per face\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0.5\n\nf 1 2 3\nf 2 4 3\nf 1 2 3 4\n",
+        "uv.obj": "v -1.5 0.25 2\nv 1e0 0 0\nv 0 1 0\nv 1 1 .5\nvt 0 0\nvt 1 0\nvt 0.25 0.75\nvt 1 1\n"
+                  "f 1/1 2/2 3/3\nf 2/2 4/4 3/3\n",
+        "uvn.obj": "o thing\nv 0 0 0\nv 2 0 0\nv 0 2 0\nv 2 2 1\nvn 0 0 1\nvn 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvt 1 1\n"
+                   "s off\nf 1/1/1 2/2/1 3/3/2\nf 2/2/1 4/4/2 3/3/1 1/1/1\n",
+        "escalate.obj": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0.5 0.5\nvt 1 0\nvt 0 1\nvn 0 0 1\n"
+                        "f 1 2 3\nf 2/2 4/1 3/3\nf 1/1/1 2/2/1 4/3/1\nf 1/2 2/3 3/1\nf 1 2 3\n",
+        "broken.obj": "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\nf 1//1 2//1 3//1\nf 1 2 3\n",
+    }
+    meta["loader_cases"] = []
+    for name, text in objs.items():
+        path = os.path.join(ldir, name)
+        with open(path, "w") as f:
+            f.write(text)
+        for origin, scale in (((0.0, 0.0, 0.0), 1.0), ((1.5, -2.0, 0.125), 2.5)):
+            tris = R.load_mesh(path, origin, scale)
+            fn = f"{name[:-4]}_s{scale}.npy"
+            np.save(os.path.join(ldir, fn), tris)
+            meta["loader_cases"].append({"obj": name, "origin": list(origin), "scale": scale, "file": fn, "triangles": len(tris)})
+    tex = S._small_texture(16, 8, 907)
+    B.write_bmp(os.path.join(ldir, "tex16x8.bmp"), tex)
+    got = R.load_texture(os.path.join(ldir, "tex16x8.bmp"))
+    assert np.array_equal(got, tex)
+    np.save(os.path.join(ldir, "tex16x8.npy"), got)
     # 2. CalcIntersect known answers: rays aimed roughly at each object kind
     sc, _, _, _, _ = S.small_case("mesh")
     p = sc.pack()

@@ -113,6 +113,10 @@ class Reference:
         L.ref_texture.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p]
         L.ref_adaptor_roundtrip.restype = C.c_int
         L.ref_adaptor_roundtrip.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        L.ref_load_mesh.restype = C.c_int
+        L.ref_load_mesh.argtypes = [C.c_char_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        L.ref_load_texture.restype = C.c_int
+        L.ref_load_texture.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int]
         self.L = L
         self.tmp = tempfile.mkdtemp(prefix="rt355_ref_")
 
@@ -128,6 +132,23 @@ class Reference:
         if rc != 0:
             raise RuntimeError(f"ref_render failed: {rc}")
         return out
+
+    def load_mesh(self, path, origin=(0.0, 0.0, 0.0), scale=1.0, cap=100000) -> np.ndarray:
+        """Mesh::Mesh(path, origin, scale) of the reference: (n, 15) float64 rows p0 p1 p2 uv0 uv1 uv2."""
+        o = np.array(origin, dtype=np.float64)
+        out = np.zeros((cap, 15), dtype=np.float64)
+        n = self.L.ref_load_mesh(str(path).encode(), o.ctypes.data, float(scale), out.ctypes.data, cap)
+        assert 0 <= n <= cap
+        return out[:n].copy()
+
+    def load_texture(self, path) -> np.ndarray:
+        """Texture::Texture(path) of the reference: (height, width, 3) uint8 in memory order (power-of-two sizes)."""
+        w, h = C.c_int(), C.c_int()
+        out = np.zeros(1 << 22, dtype=np.uint8)
+        rc = self.L.ref_load_texture(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes)
+        if rc != 0:
+            raise RuntimeError(f"ref_load_texture failed: {rc}")
+        return out[: w.value * h.value * 3].reshape(h.value, w.value, 3).copy()
 
     def adaptor_roundtrip(self, packed, shader) -> int:
         return int(self.L.ref_adaptor_roundtrip(C.byref(packed.desc), C.byref(shader.c), self.tmp.encode()))

@@ -383,6 +383,45 @@ int ref_texture(const rt355_texture *t, int kind, const double *ab, int n, unsig
     return 0;
 }
 
+// The reference's own OBJ reader: Mesh::Mesh(filePath, mesh_origin, scale) (anyobject.h:546-644).  out receives up
+// to cap triangles, 15 doubles each (p0 p1 p2 UV_p0 UV_p1 UV_p2); returns the number of triangles read.
+int ref_load_mesh(const char *path, const double *origin, double scale, double *out, int cap) {
+    std::streambuf *old = std::cout.rdbuf();
+    std::ostringstream sink;
+    std::cout.rdbuf(sink.rdbuf());
+    Mesh m(path, pnt(origin), scale, 0);
+    std::cout.rdbuf(old);
+    int n = (int)m.triangles.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        const Triangle &t = m.triangles[i];
+        double *o = out + 15 * i;
+        o[0] = t.p0.x; o[1] = t.p0.y; o[2] = t.p0.z; o[3] = t.p1.x; o[4] = t.p1.y; o[5] = t.p1.z;
+        o[6] = t.p2.x; o[7] = t.p2.y; o[8] = t.p2.z;
+        o[9] = t.UV_p0.x; o[10] = t.UV_p0.y; o[11] = t.UV_p1.x; o[12] = t.UV_p1.y; o[13] = t.UV_p2.x; o[14] = t.UV_p2.y;
+    }
+    return n;
+}
+
+// The reference's own BMP reader: Texture::Texture(filename) (texture.h:42-79).  Its texel array is private, so
+// the texels are read back through GetColorPlane at texel corners (exact when width and height are powers of
+// two: the bilinear weights are then 1, 0, 0, 0).  out receives width * height * 3 bytes in memory order.
+int ref_load_texture(const char *path, int *width, int *height, unsigned char *out, int cap) {
+    try {
+        Texture t(path, 1, 1);
+        *width = t.width; *height = t.height;
+        if ((long long)t.width * t.height * 3 > cap) return -2;
+        for (int iy = 0; iy < t.height; iy++)
+            for (int ix = 0; ix < t.width; ix++) {
+                Color c = t.GetColorPlane((double)ix / t.width, (double)iy / t.height);
+                unsigned char *o = out + ((size_t)iy * t.width + ix) * 3;
+                o[0] = c.r; o[1] = c.g; o[2] = c.b;
+            }
+        return 0;
+    } catch (const char *) {
+        return -1;
+    }
+}
+
 // Build reference objects from a descriptor, run the maintainer-side adaptor
 // (include/rt355_reference_adaptor.hpp) over them and compare what it produces with the
 // descriptor we started from.  Returns 0 when identical, else a positive code.

@@ -302,6 +302,98 @@ def read_geodesic(path) -> np.ndarray:
     return geodesic(verts)
 
 
+def read_obj(path, mesh_origin=(0.0, 0.0, 0.0), scale=1.0) -> np.ndarray:
+    """The OBJ reader of Mesh::Mesh (anyobject.h:546-644) as (n, 15) float64 rows p0 p1 p2 uv0 uv1 uv2, ready
+    for Scene.add_mesh: `v` lines become mesh_origin + p * scale, faces are read as `a b c`, then `a/p b/q c/r`,
+    then `a/p/l b/q/m c/r/n` (the format escalates when a line does not fit and stays; only the first three
+    corners count; a face that fits none ends the reading), UVs stay (0, 0) without `vt` lines.  A file that
+    cannot be opened gives no triangles, as there.  Indices are read as decimal integers (sscanf's %i also
+    takes 0x.. and 0.. prefixes, which OBJ files do not use)."""
+    import re
+    ox, oy, oz = (float(c) for c in mesh_origin)
+    scale = float(scale)
+    num = r"([+-]?\d+)"
+    formats = {1: re.compile(rf"f\s+{num}\s+{num}\s+{num}"),
+               2: re.compile(rf"f\s+{num}/{num}\s+{num}/{num}\s+{num}/{num}"),
+               3: re.compile(rf"f\s+{num}/{num}/{num}\s+{num}/{num}/{num}\s+{num}/{num}/{num}")}
+    verts, uvs, rows = [], [], []
+    n_normals, face_type, has_texture = 0, 1, False
+
+    def leading_floats(text, n):  # operator>> on an istringstream: values until one fails to parse, the rest stay 0
+        out = [0.0] * n
+        for i, tok in enumerate(text.split()[:n]):
+            try:
+                out[i] = float(tok)
+            except ValueError:
+                break
+        return out
+    try:
+        f = open(path, "r", errors="replace")
+    except OSError:
+        return np.zeros((0, 15), np.float64)
+    with f:
+        for line in f.read().split("\n"):
+            if line[:2] == "v ":
+                x, y, z = leading_floats(line[2:], 3)
+                verts.append((ox + (x - 0) * scale, oy + (y - 0) * scale, oz + (z - 0) * scale))
+            elif line[:2] == "vt":
+                has_texture = True
+                uvs.append(tuple(leading_floats(line[2:], 2)))
+            elif line[:2] == "vn":
+                n_normals += 1
+            elif line[:2] == "f ":
+                idx = None
+                while face_type <= 3:
+                    m = formats[face_type].match(line)
+                    if m:
+                        idx = [int(g) for g in m.groups()]
+                        break
+                    face_type += 1
+                if idx is None:
+                    break
+                per = face_type  # numbers per corner
+                a, b, c = idx[0], idx[per], idx[2 * per]
+                p, q, r = (idx[1], idx[per + 1], idx[2 * per + 1]) if per >= 2 else (1, 1, 1)
+                if not all(1 <= i <= len(verts) for i in (a, b, c)):
+                    raise ValueError(f"{path}: face refers to a vertex that was not read: {line}")
+                uv = [(0.0, 0.0)] * 3
+                if has_texture:
+                    if not all(1 <= i <= len(uvs) for i in (p, q, r)):
+                        raise ValueError(f"{path}: face refers to a texture coordinate that was not read: {line}")
+                    uv = [uvs[p - 1], uvs[q - 1], uvs[r - 1]]
+                rows.append([*verts[a - 1], *verts[b - 1], *verts[c - 1], *uv[0], *uv[1], *uv[2]])
+    return np.array(rows, dtype=np.float64).reshape(-1, 15)
+
+
+def read_bmp(path) -> np.ndarray:
+    """Texture::Texture (texture.h:42-79): 54-byte header, width at byte 18, height at byte 22, then
+    3 * width * height bytes as they come (no row padding, bottom row first), B and R swapped.  Returns
+    (height, width, 3) uint8 in the reference's in-memory order, ready for Scene.add_texture."""
+    with open(path, "rb") as f:
+        info = f.read(54).ljust(54, b"\0")
+        w = int.from_bytes(info[18:22], "little", signed=True)
+        h = int.from_bytes(info[22:26], "little", signed=True)
+        if w <= 0 or h <= 0:
+            raise ValueError(f"{path}: bad size in the header")
+        px = np.frombuffer(f.read(3 * w * h).ljust(3 * w * h, b"\0"), dtype=np.uint8).reshape(h, w, 3)
+    return np.ascontiguousarray(px[:, :, ::-1])
+
+
+def write_bmp(path, rgb: np.ndarray):
+    """A 24-bit BMP the way Texture::Texture reads one: rgb is (height, width, 3) in memory order (row 0 = the
+    file's first row); rows are NOT padded, which is what that reader assumes."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    hdr = bytearray(54)
+    hdr[0:2] = b"BM"
+    hdr[2:6] = (54 + 3 * w * h).to_bytes(4, "little")
+    hdr[10] = 54; hdr[14] = 40; hdr[26] = 1; hdr[28] = 24
+    hdr[18:22] = w.to_bytes(4, "little"); hdr[22:26] = h.to_bytes(4, "little")
+    with open(path, "wb") as f:
+        f.write(bytes(hdr))
+        f.write(rgb[:, :, ::-1].tobytes())
+
+
 def icosphere(level=1):
     """Vertices of an icosahedron subdivided `level` times (12, 42, 162, 642 ... points on the unit sphere):
     a stand-in for the reference's geodesic.obj, which its repository does not hold."""

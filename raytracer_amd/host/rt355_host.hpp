@@ -9,6 +9,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -43,6 +44,30 @@ struct Color { // color.h:16-31
 
 struct Texture { // a loaded texture.h Texture: texels in memory order, scale factors
     std::vector<unsigned char> rgb; int width = 0, height = 0; double sx = 1, sy = 1;
+    Texture() {}
+    // Texture(string filename, double sx, double sy) of texture.h:42-79: a 54-byte header with the width at
+    // byte 18 and the height at byte 22, then 3 * width * height bytes taken as they come (no row padding,
+    // no bit-depth check, bottom row first), B and R swapped in place.  A file that cannot be opened is an
+    // error here as it is there (`throw "Argument Exception"`, texture.h:52); a file shorter than its header
+    // promises leaves the missing texels 0 (the reference leaves them uninitialised).
+    explicit Texture(const std::string &filename, double sx_in = 1, double sy_in = 1) : sx(sx_in), sy(sy_in) {
+        FILE *fp = std::fopen(filename.c_str(), "rb");
+        if (!fp) throw Error("cannot open texture " + filename);
+        unsigned char info[54];
+        std::memset(info, 0, sizeof info);
+        size_t got = std::fread(info, 1, 54, fp);
+        (void)got;
+        std::memcpy(&width, info + 18, 4);
+        std::memcpy(&height, info + 22, 4);
+        if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) {
+            std::fclose(fp);
+            throw Error("texture " + filename + ": bad size in the header");
+        }
+        rgb.assign((size_t)3 * width * height, 0);
+        got = std::fread(rgb.data(), 1, rgb.size(), fp);
+        std::fclose(fp);
+        for (size_t i = 0; i + 2 < rgb.size(); i += 3) std::swap(rgb[i], rgb[i + 2]);
+    }
 };
 
 class AnyObject { // anyobject.h:17-36
@@ -73,16 +98,73 @@ public:
 };
 
 struct Triangle { // anyobject.h:444-532 (data members only)
-    Point3D p0, p1, p2; Vector2D UV_p0{0, 0}, UV_p1{1, 0}, UV_p2{0, 1};
+    Point3D p0, p1, p2; Vector2D UV_p0, UV_p1, UV_p2; // (0, 0) until SetUV, as the reference's members are
     Triangle(Point3D a, Point3D b, Point3D c) : p0(a), p1(b), p2(c) {}
     void SetUV(Vector2D t0, Vector2D t1, Vector2D t2) { UV_p0 = t0; UV_p1 = t1; UV_p2 = t2; }
 };
 
-class Mesh : public AnyObject { // anyobject.h:534-675; triangles are supplied, not parsed
+class Mesh : public AnyObject { // anyobject.h:534-675
 public:
     Color clr{150, 200, 110};
     std::vector<Triangle> triangles;
     explicit Mesh(std::vector<Triangle> tris = {}, double ks_in = 0) : triangles(std::move(tris)) { ks = ks_in; }
+    // Mesh(string filePath, Point3D mesh_origin, double scale, double ks) of anyobject.h:546-644, line by line:
+    // `v` lines become mesh_origin + (p - 0) * scale, `vt` lines texture coordinates, `vn` lines are counted
+    // (vertex normals are stored by the reference and used nowhere on the path), `f` lines are read with
+    // sscanf as `a b c`, then `a/p b/q c/r`, then `a/p/l b/q/m c/r/n` -- the format escalates when a line does
+    // not fit and never goes back; only the first three corners of a face are used; a face that fits none of
+    // the formats ends the reading with what was read so far, and a file that cannot be opened gives an
+    // empty mesh (the reference reports both on cout and carries on).  An index outside the lists read so
+    // far is undefined behaviour there and an Error here.
+    explicit Mesh(const std::string &filePath, Point3D mesh_origin = Point3D(0, 0, 0), double scale = 1, double ks_in = 0) {
+        ks = ks_in;
+        std::ifstream ifs(filePath.c_str());
+        if (ifs.fail()) return;
+        std::vector<Point3D> vertices;
+        std::vector<Vector2D> UVs;
+        size_t n_normals = 0;
+        std::string line;
+        int face_type = 1;
+        bool has_normal = false, has_texture = false;
+        while (ifs.peek() != EOF) {
+            std::getline(ifs, line);
+            if (line.substr(0, 2) == "v ") {
+                std::istringstream v(line.substr(2));
+                double x = 0, y = 0, z = 0;
+                v >> x; v >> y; v >> z;
+                vertices.push_back(Point3D(mesh_origin.x + (x - 0) * scale, mesh_origin.y + (y - 0) * scale,
+                                           mesh_origin.z + (z - 0) * scale));
+            } else if (line.substr(0, 2) == "vt") {
+                has_texture = true;
+                std::istringstream v(line.substr(2));
+                double x = 0, y = 0;
+                v >> x; v >> y;
+                UVs.push_back(Vector2D(x, y));
+            } else if (line.substr(0, 2) == "vn") {
+                has_normal = true;
+                n_normals++;
+            } else if (line.substr(0, 2) == "f ") {
+                int a = 1, b = 1, c = 1, p = 1, q = 1, r = 1, l = 1, m = 1, n = 1;
+                const char *chh = line.c_str();
+                if (face_type == 1 && std::sscanf(chh, "f %i %i %i", &a, &b, &c) != 3) face_type = 2;
+                if (face_type == 2 && std::sscanf(chh, "f %i/%i %i/%i %i/%i", &a, &p, &b, &q, &c, &r) != 6) face_type = 3;
+                if (face_type == 3 && std::sscanf(chh, "f %i/%i/%i %i/%i/%i %i/%i/%i", &a, &p, &l, &b, &q, &m, &c, &r, &n) != 9)
+                    return;
+                auto in = [](int i, size_t size) { return i >= 1 && (size_t)i <= size; };
+                if (!in(a, vertices.size()) || !in(b, vertices.size()) || !in(c, vertices.size()))
+                    throw Error(filePath + ": face refers to a vertex that was not read: " + line);
+                Triangle tri(vertices[a - 1], vertices[b - 1], vertices[c - 1]);
+                if (has_normal && (!in(l, n_normals) || !in(m, n_normals) || !in(n, n_normals)))
+                    throw Error(filePath + ": face refers to a normal that was not read: " + line);
+                if (has_texture) {
+                    if (!in(p, UVs.size()) || !in(q, UVs.size()) || !in(r, UVs.size()))
+                        throw Error(filePath + ": face refers to a texture coordinate that was not read: " + line);
+                    tri.SetUV(UVs[p - 1], UVs[q - 1], UVs[r - 1]);
+                }
+                triangles.push_back(tri);
+            }
+        }
+    }
     const std::string GetObjectType() const override { return "Mesh"; }
 };
 
