@@ -28,6 +28,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             raise Rt355Error(f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        # A process must hold ONE HIP runtime.  PyTorch ships its own libamdhip64; if it is going to be used in
+        # this process (bench.py, the tests) it has to be loaded first so that this library binds to the same
+        # copy -- loaded the other way round, the second runtime finds no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIB_PATH)
         L.rt355_last_error.restype = C.c_char_p
         L.rt355_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

@@ -14,7 +14,9 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(so):
         import __graft_entry__ as g
         g.build()
-    L = ctypes.CDLL(so)
+    from raytracer_amd import api
+    assert os.path.samefile(api._LIB_PATH, so) or os.environ.get("RT355_LIB")
+    L = api.lib()  # loads PyTorch's HIP runtime first when PyTorch is present (one runtime per process)
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in rt355.h but not exported"
     L.rt355_abi_version.restype = ctypes.c_int
