@@ -167,6 +167,20 @@ def shade_bytes(stats, n_rays_padded, n_lights, w, h, searched):
     return float(n_rays_padded * 4 + hits * 88 + (stats["shadow_rays"] * 4 + cands * 4 if searched else 0) + w * h * 3)
 
 
+def measured_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` on `workload` as the PMC counters gave them (rocprofv3 --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE, separate passes of this same bench command: tools/traffic_passes.sh), read from the
+    committed summary; FETCH_SIZE doubled, as gfx950 tallies a 128-byte request as 64 bytes.  None when the
+    summary does not hold the pair."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        rec = json.load(open(path))[workload][kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+    return {"bytes": (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0, "fetch_kib_counter": rec["fetch_kb"],
+            "write_kib_counter": rec["write_kb"], "source": "profiles/r1_traffic.json"}
+
+
 def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None, detail=False):
     """`steps` frames back to back, each synchronised before the next is enqueued.  With detail=True the
     HIP-event kernel times of every frame are read back and summed (not done inside timed regions)."""
@@ -312,6 +326,11 @@ def measure(name, args, ctx, headline):
         dominant = max(rooflines, key=lambda k: times[k])
         out["roofline"] = rooflines[dominant]
         out["roofline_other_kernels"] = {k: v for k, v in rooflines.items() if k != dominant}
+    for rf in [out["roofline"], *out.get("roofline_other_kernels", {}).values()]:
+        t = measured_traffic(name, rf["kernel"]) if args.mode == "packet" else None
+        if t:
+            rf["traffic"] = t["bytes"]
+            rf["traffic_detail"] = t
     if world == 1 and args.mode == "packet" and not args.no_allpairs and searched:
         o2 = B.opts(w, h, mode=B.MODE_ALLPAIRS)
         run_frames(r, cam, shader, o2, fb, stream, 1)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# HBM-side traffic of every kernel of the bench workloads: one FETCH_SIZE pass and one WRITE_SIZE pass each
+# (the two do not fit one pass), merged into gpurun_out/traffic.json by tools/traffic_merge.py.
+# Usage (GPU box): bash tools/traffic_passes.sh <workload> [...]
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+for wl in "$@"; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    tag=traffic_${wl}_$c
+    timeout -s KILL 150 rocprofv3 --pmc $c -d gpurun_out/$tag -- python3 bench.py --steps 3 --warmup 1 --workload $wl --no-others --no-allpairs --no-cpu-baseline > gpurun_out/$tag.log 2>&1 || { tail -n 5 gpurun_out/$tag.log; exit 1; }
+    db=$(find gpurun_out/$tag -name '*.db' | head -n 1)
+    python3 tools/prof_summary.py "$db" > gpurun_out/$tag.txt 2>&1 || exit 1
+  done
+done
+python3 tools/traffic_merge.py "$@" > gpurun_out/traffic.json && cat gpurun_out/traffic.json | head -c 1500
