@@ -245,6 +245,28 @@ def test_full_size_properties(api, oracle):
     r.close()
 
 
+def test_full_size_gather(api, oracle):
+    """The renderer HEAD of the reference selects, at the metric's size: the default scene at 3840x2160 under
+    shading3 with 42 gather directions (350 M rays), whole-frame hash and ray count equal to the CPU checker's;
+    and with 162 directions two row slabs equal the frame rendered at once."""
+    w, h = 3840, 2160
+    sc, sh, cam = S.default_scene(), S.default_shader(1), S.default_camera(w, h)
+    r = api.Renderer(sc)
+    dirs = B.geodesic(B.icosphere(1))
+    r.set_directions(dirs)
+    got, st = r.render(cam, sh, w, h, seed=2024, shading=B.SHADING_BLEED)
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, seed=2024, shading=B.SHADING_BLEED), threads=0, dirs=dirs)
+    assert st["gather_rays"] == wst["gather_rays"] > 100_000_000
+    assert oracle.fnv(got) == oracle.fnv(want)
+    r.set_directions(B.geodesic(B.icosphere(2)))
+    whole, _ = r.render(cam, sh, w, h, seed=7, shading=B.SHADING_BLEED)
+    parts = np.zeros_like(whole)
+    r.render(cam, sh, w, h, row_begin=0, row_end=777, out=parts, seed=7, shading=B.SHADING_BLEED)
+    r.render(cam, sh, w, h, row_begin=777, row_end=h, out=parts, seed=7, shading=B.SHADING_BLEED)
+    assert np.array_equal(parts, whole)
+    r.close()
+
+
 def test_error_behaviour(api):
     sc = S.default_scene()
     sc.objects[2]["fresnel"] = 0.5
