@@ -74,6 +74,7 @@ __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, u
 #define CAND_SPHERE 0x40000000u
 #define CAND_TRI 0x80000000u
 #define CAND_INDEX 0x3fffffffu
+#define CAND_UNSEARCHED 0xffffffffu // candidate count of a ray the search left to the fp64 walk over everything
 #ifndef CAND_BATCH
 #define CAND_BATCH 2        // candidates whose ids and records are loaded together by the exact tests
 #endif
@@ -104,6 +105,9 @@ struct Frame {
     int32_t grid_w, grid_h;
     int32_t alias;
     uint32_t seed;
+    // Reflection on searched scenes renders a frame level by level (camera rays, their mirror rays, ...): the
+    // shading of level `level` >= 0 goes to Work::lvl_clr and k_fold writes the pixels; -1 = no levels.
+    int32_t level;
 };
 // inverse of rid_to_xy
 __device__ __forceinline__ uint32_t xy_to_rid(int x, int y, int tiles_x) {
@@ -136,6 +140,12 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *bin_id;     // [n] packet search: direction bin of each ray, 0xffffffff = inactive
     uint32_t *bin_rank;   // [n] packet search: rank of the ray among those of its counter
     uint32_t tile_stride, list_stride;
+    // reflection on searched scenes (allocated when such a frame is rendered), all [..][n]
+    uint32_t *lvl_clr;    // [4] colour Shader::shading gave the ray of each level
+    double *lvl_ks;       // [4] ks of the object the ray of each level hit (objs[0]'s on a miss, main.cpp:94)
+    double *ktotal;       // reflection_ktotal after the deepest level so far
+    uint32_t *deepest;    // deepest level the chain of this sub-sample reached
+    double *ray_d;        // [6] the ray of the level being traced: pe.xyz, npe.xyz
 };
 
 // Kernels that work on the rays of several lights at once take the workspace slot from blockIdx.y
@@ -1175,6 +1185,121 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
 #endif
 }
 
+// ---- search for rays that share neither origin nor direction (mirror rays) -----------------------------
+// The tables above are built around one origin or one direction.  Mirror rays have neither, so they are
+// searched against a table of the SCENE instead, built once per scene on the host: the bounding spheres of
+// all spheres and triangles in Morton order of their centres, a bounding sphere for every 64 of them (a
+// chunk) and for every 64 chunks.  A wave bounds its 64 rays by a ball around their origins and a cone around
+// their directions; a sphere (c, R) can only be hit by one of them if c lies within R + rho of the origin
+// ball's centre C or within the cone widened by asin((R + rho) / |c - C|).  Superchunks, chunks and
+// primitives are tested against that beam 64 at a time (one per lane, one ballot), and the primitives that
+// pass are tested ray by ray: distance of the centre from the ray's line, and not behind the origin.  All
+// in fp32 with margins that cover the rounding of the rays to fp32 and of the arithmetic, so that a true hit
+// is never lost; what passes goes to the ray's candidate list for the fp64 tests.  Planes are candidates
+// of every ray.
+struct GeneralTable {
+    const float4 *prim;      // [n_prims_pad] centre, radius (rounded up); NaN = padding
+    const uint32_t *prim_id; // [n_prims_pad] candidate id (primitive index | kind bits)
+    const float4 *chunk;     // [n_chunks_pad] bounding sphere of prim[64 j .. 64 j + 63]
+    const float4 *super;     // [n_supers] bounding sphere of chunk[64 k .. 64 k + 63]
+    const uint32_t *plane_id;// [n_planes] candidate ids of the planes
+    int32_t n_supers, n_planes;
+};
+struct Beam { float cx, cy, cz, rho, ax, ay, az, theta; };
+// may a ray of the beam hit the sphere q?  (NaN q: no)
+__device__ __forceinline__ bool beam_meets(const Beam &b, const float4 &q) {
+    const float vx = q.x - b.cx, vy = q.y - b.cy, vz = q.z - b.cz;
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float reach = (q.w + b.rho) * 1.00001f + 1e-6f * (1.0f + fabsf(q.x) + fabsf(q.y) + fabsf(q.z));
+    if (!(d == d) || !(reach == reach)) return false;
+    if (d * 0.99f <= reach) return true;                 // the origin ball touches the sphere (or nearly: asin gets steep)
+    const float inv = 1.0f / d;
+    const float ex = vx * inv - b.ax, ey = vy * inv - b.ay, ez = vz * inv - b.az;
+    const float chord = sqrtf(ex * ex + ey * ey + ez * ez); // between two unit vectors: angle = 2 asin(chord / 2)
+    const float ang = 2.0f * asinf(fminf(1.0f, 0.5f * chord));
+    return ang <= b.theta + asinf(reach * inv) + 2e-5f;
+}
+// may the ray (o, u) hit the sphere q?
+__device__ __forceinline__ bool ray_meets(float ox, float oy, float oz, float ux, float uy, float uz, float o_l1,
+                                          const float4 &q) {
+    const float vx = q.x - ox, vy = q.y - oy, vz = q.z - oz;
+    const float along = vx * ux + vy * uy + vz * uz;
+    const float wx = vx - along * ux, wy = vy - along * uy, wz = vz - along * uz; // centre minus its foot on the line
+    const float dist2 = wx * wx + wy * wy + wz * wz;
+    const float len = fabsf(vx) + fabsf(vy) + fabsf(vz);
+    const float reach = q.w + 3.8146973e-06f * (len + o_l1 + fabsf(q.x) + fabsf(q.y) + fabsf(q.z) + 1.0f); // 2^-18
+    return dist2 <= reach * reach * 1.00001f && along >= -reach;
+}
+__global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const double *__restrict__ ray_d,
+                                                        const uint32_t *__restrict__ deepest, uint32_t level,
+                                                        uint32_t n_rays, uint32_t *__restrict__ cand,
+                                                        uint32_t *__restrict__ cand_cnt, Spill sp,
+                                                        unsigned long long *__restrict__ counters) {
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // n_rays is a multiple of the block size
+    const int lane = threadIdx.x & 63;
+    const size_t n = n_rays;
+    bool active = deepest[rid] == level;
+    float ox = 0, oy = 0, oz = 0, ux = 0, uy = 0, uz = 0;
+    bool odd = false; // a ray the beam cannot hold (no direction, not finite): left to the fp64 walk
+    if (active) {
+        ox = (float)ray_d[0 * n + rid]; oy = (float)ray_d[1 * n + rid]; oz = (float)ray_d[2 * n + rid];
+        ux = (float)ray_d[3 * n + rid]; uy = (float)ray_d[4 * n + rid]; uz = (float)ray_d[5 * n + rid];
+        const float ul = ux * ux + uy * uy + uz * uz, ol = fabsf(ox) + fabsf(oy) + fabsf(oz);
+        odd = !(ul > 0.99f && ul < 1.01f) || !(ol < 1e15f);
+    }
+    const bool in_beam = active && !odd;
+    const float n_in = wave_sum_f(in_beam ? 1.0f : 0.0f);
+    uint32_t cnt = 0, n_pairs = 0;
+    if (n_in > 0.0f) { // uniform
+        Beam b;
+        b.cx = wave_sum_f(in_beam ? ox : 0.0f) / n_in; b.cy = wave_sum_f(in_beam ? oy : 0.0f) / n_in;
+        b.cz = wave_sum_f(in_beam ? oz : 0.0f) / n_in;
+        const float dx = ox - b.cx, dy = oy - b.cy, dz = oz - b.cz;
+        b.rho = wave_max_f(in_beam ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.0f);
+        b.rho = b.rho * 1.00001f + 2e-6f * (1.0f + fabsf(b.cx) + fabsf(b.cy) + fabsf(b.cz));
+        float sx = wave_sum_f(in_beam ? ux : 0.0f), sy = wave_sum_f(in_beam ? uy : 0.0f), sz = wave_sum_f(in_beam ? uz : 0.0f);
+        const float sl = sqrtf(sx * sx + sy * sy + sz * sz);
+        if (sl > 1e-3f * n_in) {
+            b.ax = sx / sl; b.ay = sy / sl; b.az = sz / sl;
+            const float ex = ux - b.ax, ey = uy - b.ay, ez = uz - b.az;
+            const float ang = 2.0f * asinf(fminf(1.0f, 0.5f * sqrtf(ex * ex + ey * ey + ez * ez)));
+            b.theta = wave_max_f(in_beam ? ang : 0.0f) + 2e-5f;
+        } else { // the directions all but cancel: no cone
+            b.ax = 1.0f; b.ay = 0.0f; b.az = 0.0f; b.theta = 4.0f;
+        }
+        const float o_l1 = fabsf(ox) + fabsf(oy) + fabsf(oz);
+        if (in_beam)
+            for (int p = 0; p < t.n_planes; p++) append_id(t.plane_id[p], rid, n_rays, cand, cnt, sp);
+        for (int s0 = 0; s0 < t.n_supers; s0 += 64) {
+            const bool meets_s = (s0 + lane < t.n_supers) && beam_meets(b, t.super[s0 + lane]);
+            unsigned long long ms = __ballot(meets_s);
+            while (ms) { // uniform
+                const int k = s0 + __builtin_ctzll(ms);
+                ms &= ms - 1;
+                unsigned long long mc = __ballot(beam_meets(b, t.chunk[(size_t)k * 64 + lane]));
+                while (mc) {
+                    const size_t j = (size_t)k * 64 + (size_t)__builtin_ctzll(mc);
+                    mc &= mc - 1;
+                    const float4 q = t.prim[j * 64 + lane];
+                    const uint32_t qid = t.prim_id[j * 64 + lane];
+                    unsigned long long mp = __ballot(beam_meets(b, q));
+                    while (mp) {
+                        const int l = __builtin_ctzll(mp);
+                        mp &= mp - 1;
+                        float4 one;
+                        one.x = lane_bcast(q.x, l); one.y = lane_bcast(q.y, l); one.z = lane_bcast(q.z, l); one.w = lane_bcast(q.w, l);
+                        const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)qid, l);
+                        n_pairs += in_beam ? 1u : 0u;
+                        if (in_beam && ray_meets(ox, oy, oz, ux, uy, uz, o_l1, one)) append_id(id, rid, n_rays, cand, cnt, sp);
+                    }
+                }
+            }
+        }
+    }
+    cand_cnt[rid] = (active && odd) ? CAND_UNSEARCHED : cnt;
+    wave_count(counters, 5, n_pairs);
+}
+
 // ---- fp64 closest hit over a ray's candidates (or over everything) -----------------------------------
 // The candidates of a ray come in table order, not list order, so the list-order rules of the
 // reference are restated without order: the closest-hit loop (main.cpp:65-79) keeps the FIRST object
@@ -1193,7 +1318,8 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
     uint32_t n = 0, n_spill = 0;
     if (!brute) {
         n = cand_cnt[rid];
-        if (n > CAND_CAP) { // the rest is in the bundle's spill list, unless that overflowed too
+        if (n == CAND_UNSEARCHED) { brute = true; n = 0; }
+        else if (n > CAND_CAP) { // the rest is in the bundle's spill list, unless that overflowed too
             overflowed += 1;
             n_spill = *sp.count;
             if (n_spill > POOL_CAP) brute = true;
@@ -1316,6 +1442,7 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
 // the colour of grid point (x, y): a pixel of the frame, or a sub-sample kept for k_average
 __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, const Frame &f, const Work &w,
                                             uint32_t rid, int x, int y, uint32_t clr) {
+    if (f.level >= 0) { w.lvl_clr[(size_t)f.level * w.n + rid] = clr; return; }
     if (f.alias > 0) { w.rec_sum[rid] = clr; return; }
     size_t i = ((size_t)(y + f.row_begin) * (size_t)f.width + (size_t)x) * 3;
     pixmap[i] = (unsigned char)cr(clr); pixmap[i + 1] = (unsigned char)cg(clr); pixmap[i + 2] = (unsigned char)cb(clr);
@@ -1703,6 +1830,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
                                                          unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_eval = 0, n_over = 0, n_hit = 0;
+    bool got_hit = false;
     d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
     do {
     if (rid >= f.n_rays) break;
@@ -1712,7 +1840,15 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         w.rec_obj[rid] = -2;
         break;
     }
-    Ray e = grid_ray(cam, f, x, y);
+    Ray e;
+    if (f.level > 0) { // the mirror rays of level f.level (k_reflect_rays left them in ray_d); -2 = this chain has ended
+        if (w.deepest[rid] != (uint32_t)f.level) { w.rec_obj[rid] = -2; break; }
+        const size_t n = f.n_rays;
+        e.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
+        e.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
+    } else {
+        e = grid_ray(cam, f, x, y);
+    }
     Closest c;
     closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
@@ -1720,14 +1856,16 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
-    n_hit = 1;
-    if (sh.n_lights == 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
+    n_hit = f.level > 0 ? 0 : 1; // rt355_stats.primary_hits counts camera rays
+    if (sh.n_lights == 0 && f.level < 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
         w.rec_obj[rid] = s.prim_obj[c.prim_best];
         store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
+    if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u); // (levels: the mirror ray still needs ph and nh)
     const HitRec h = primary_record(s, sh, e, c);
     ph = h.ph; nh = h.nh;
+    got_hit = true;
     const size_t n = f.n_rays;
     w.rec_obj[rid] = h.obj;
     w.rec_d[0 * n + rid] = ph.x; w.rec_d[1 * n + rid] = ph.y; w.rec_d[2 * n + rid] = ph.z;
@@ -1737,11 +1875,69 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u);
     w.rec_cm1[rid] = h.cm1;
     } while (0);
-    const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, n_hit && sh.n_lights, ph, nh);
+    const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, got_hit && sh.n_lights, ph, nh);
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 2, n_over);
+}
+
+// The reflection step of CalcSubPixel (main.cpp:93-108) for the rays of level `level`, after their shading:
+// ks of the object hit (objs[0]'s after a miss, whose ph and nh are zero: object_index is still 0 at
+// main.cpp:94), reflection_ktotal *= ks, reflection_times = level + 1, and while both thresholds hold
+// (main.cpp:27-28,103) the mirror ray View(ph, npe - nh * 2 * (nh . npe)), which becomes the ray of level + 1.
+__global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, Frame f, Work w, int level) {
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_secondary = 0;
+    do {
+    if (rid >= f.n_rays) break;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    const size_t n = f.n_rays;
+    if (!(x < f.grid_w && y < f.grid_h)) { if (level == 0) w.deepest[rid] = 0xffffffffu; break; }
+    if (level == 0) { w.deepest[rid] = 0u; w.ktotal[rid] = 1.0; }
+    else if (w.deepest[rid] != (uint32_t)level) break;
+    Ray e;
+    if (level == 0) e = grid_ray(cam, f, x, y);
+    else {
+        e.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
+        e.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
+    }
+    const int obj = w.rec_obj[rid];
+    const double ks = s.n_objects > 0 ? s.objects[obj >= 0 ? obj : 0].ks : 0.0; // main.cpp:94
+    w.lvl_ks[(size_t)level * n + rid] = ks;
+    const double ktotal = w.ktotal[rid] * ks;                                    // :97
+    w.ktotal[rid] = ktotal;
+    if (!((level + 1 <= 3) && (ktotal >= 0.05) && s.n_objects > 0)) break;       // :98-103
+    d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
+    if (obj >= 0) {
+        ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
+        nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+    }
+    const Ray r = mkview(ph, vsub(e.npe, vmul(vmul(nh, 2), dot(nh, e.npe))));   // :104-108
+    w.ray_d[0 * n + rid] = r.pe.x; w.ray_d[1 * n + rid] = r.pe.y; w.ray_d[2 * n + rid] = r.pe.z;
+    w.ray_d[3 * n + rid] = r.npe.x; w.ray_d[4 * n + rid] = r.npe.y; w.ray_d[5 * n + rid] = r.npe.z;
+    w.deepest[rid] = (uint32_t)level + 1u;
+    n_secondary = 1;
+    } while (0);
+    wave_count(w.counters, 6, n_secondary);
+}
+
+// clr * (1 - ks) + CalcSubPixel(mirror ray) * ks from the deepest level back (main.cpp:109), then the pixel
+__global__ __launch_bounds__(256) void k_fold_levels(Frame f, Work w, unsigned char *__restrict__ pixmap) {
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rid >= f.n_rays) return;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    if (!(x < f.grid_w && y < f.grid_h)) return;
+    const size_t n = f.n_rays;
+    const int deepest = (int)w.deepest[rid];
+    uint32_t clr = w.lvl_clr[(size_t)deepest * n + rid];
+    for (int level = deepest - 1; level >= 0; level--) {
+        const double ks = w.lvl_ks[(size_t)level * n + rid];
+        clr = cadd(cmul(w.lvl_clr[(size_t)level * n + rid], 1 - ks), cmul(clr, ks));
+    }
+    store_pixel(pixmap, f, w, rid, x, y, clr); // f.level is -1 here: the frame, or the sub-sample sums of k_average
 }
 
 // Shader::shading's loop over the lights (shader.h:60-94) for the lights of one group: colour before
@@ -1907,6 +2103,9 @@ struct rt355_scene {
     int work_slots = 0, table_slots = 0;
     DLight *d_lights = nullptr; int lights_cap = 0;
     double *d_dirs = nullptr; int n_dirs = 0; // direction set of the gather shaders
+    GeneralTable general{};                     // scene table for mirror rays (reflective scenes that are searched)
+    bool has_general = false;
+    double ks_abs_max = 0;                      // largest |ks| of the scene
     // timing / stats of the outstanding render
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_search; // begin/end pairs
@@ -1954,6 +2153,102 @@ static int upload(rt355_scene *sc, const std::vector<T> &v, const T **out) {
     return RT355_OK;
 }
 
+// The scene table of k_search_general: bounding spheres of the spheres and triangles in Morton order of their
+// centres, of every 64 of them and of every 64 of those.  Radii are rounded up and carry what the rounding of
+// the centres to fp32 moved them by, so every sphere of the table contains what it stands for.
+namespace {
+inline float round_up(double x) {
+    float f = (float)x;
+    return ((double)f < x) ? nextafterf(f, INFINITY) : f;
+}
+inline uint64_t spread21(uint64_t v) { // 21 bits -> every third bit
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+struct BoundSphere { double c[3]; double r; uint32_t id; };
+// smallest-effort enclosing sphere of a run of spheres: centre = mean of their centres
+inline BoundSphere enclose(const BoundSphere *b, size_t count) {
+    BoundSphere o{};
+    for (size_t i = 0; i < count; i++) for (int a = 0; a < 3; a++) o.c[a] += b[i].c[a] / (double)count;
+    for (size_t i = 0; i < count; i++) {
+        double dx = b[i].c[0] - o.c[0], dy = b[i].c[1] - o.c[1], dz = b[i].c[2] - o.c[2];
+        o.r = std::max(o.r, sqrt(dx * dx + dy * dy + dz * dz) * (1 + 1e-12) + b[i].r);
+    }
+    return o;
+}
+inline float4 to_row(const BoundSphere &b) {
+    float4 q = make_float4((float)b.c[0], (float)b.c[1], (float)b.c[2], 0.f);
+    double dx = b.c[0] - (double)q.x, dy = b.c[1] - (double)q.y, dz = b.c[2] - (double)q.z;
+    q.w = round_up((b.r + sqrt(dx * dx + dy * dy + dz * dz)) * (1 + 1e-9) + 1e-300);
+    return q;
+}
+} // namespace
+static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs, const std::vector<DTriangle> &tris,
+                               const std::vector<int32_t> &prim_obj, const std::vector<int32_t> &prim_tri) {
+    std::vector<BoundSphere> prims;
+    std::vector<uint32_t> planes;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t p = 0; p < prim_obj.size(); p++) {
+        const DObject &o = objs[prim_obj[p]];
+        BoundSphere b{};
+        if (prim_tri[p] >= 0) {
+            const DTriangle &t = tris[prim_tri[p]];
+            for (int a = 0; a < 3; a++) b.c[a] = (t.p0[a] + t.p1[a] + t.p2[a]) / 3.0;
+            for (const double *v : {t.p0, t.p1, t.p2}) {
+                double dx = v[0] - b.c[0], dy = v[1] - b.c[1], dz = v[2] - b.c[2];
+                b.r = std::max(b.r, sqrt(dx * dx + dy * dy + dz * dz) * (1 + 1e-12));
+            }
+            b.id = (uint32_t)p | CAND_TRI;
+        } else if (o.type == RT_OBJ_SPHERE) {
+            for (int a = 0; a < 3; a++) b.c[a] = o.p[a];
+            b.r = fabs(o.radius);
+            b.id = (uint32_t)p | CAND_SPHERE;
+        } else {
+            planes.push_back((uint32_t)p);
+            continue;
+        }
+        if (!(std::isfinite(b.c[0]) && std::isfinite(b.c[1]) && std::isfinite(b.c[2]) && std::isfinite(b.r)))
+            return fail(RT355_ERR_ARG, "primitive " + std::to_string(p) + ": coordinates are not finite");
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.c[a]); hi[a] = std::max(hi[a], b.c[a]); }
+        prims.push_back(b);
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> order(prims.size());
+    for (size_t i = 0; i < prims.size(); i++) {
+        uint64_t code = 0;
+        for (int a = 0; a < 3; a++) {
+            const double span = hi[a] - lo[a];
+            const double u = span > 0 ? (prims[i].c[a] - lo[a]) / span : 0.0;
+            code |= spread21((uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0))) << a;
+        }
+        order[i] = {code, (uint32_t)i};
+    }
+    std::sort(order.begin(), order.end());
+    std::vector<BoundSphere> sorted(prims.size());
+    for (size_t i = 0; i < prims.size(); i++) sorted[i] = prims[order[i].second];
+    const size_t n_chunks = (sorted.size() + 63) / 64, n_supers = (n_chunks + 63) / 64;
+    const float nanf_ = nanf("");
+    std::vector<float4> prim_rows(n_supers * 4096, make_float4(nanf_, nanf_, nanf_, nanf_)), chunk_rows(n_supers * 64, make_float4(nanf_, nanf_, nanf_, nanf_)), super_rows(n_supers);
+    std::vector<uint32_t> prim_ids(n_supers * 4096, 0u);
+    std::vector<BoundSphere> chunks(n_chunks);
+    for (size_t i = 0; i < sorted.size(); i++) { prim_rows[i] = to_row(sorted[i]); prim_ids[i] = sorted[i].id; }
+    for (size_t j = 0; j < n_chunks; j++) {
+        chunks[j] = enclose(&sorted[j * 64], std::min<size_t>(64, sorted.size() - j * 64));
+        chunk_rows[j] = to_row(chunks[j]);
+    }
+    for (size_t k = 0; k < n_supers; k++) super_rows[k] = to_row(enclose(&chunks[k * 64], std::min<size_t>(64, n_chunks - k * 64)));
+    GeneralTable &g = sc->general;
+    int rc;
+    if ((rc = upload(sc, prim_rows, &g.prim)) || (rc = upload(sc, prim_ids, &g.prim_id)) || (rc = upload(sc, chunk_rows, &g.chunk)) ||
+        (rc = upload(sc, super_rows, &g.super)) || (rc = upload(sc, planes, &g.plane_id)))
+        return rc;
+    g.n_supers = (int32_t)n_supers; g.n_planes = (int32_t)planes.size();
+    sc->has_general = true;
+    return RT355_OK;
+}
+
 extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) {
     if (!d || !out) return fail(RT355_ERR_ARG, "rt355_scene_create: null argument");
     if (d->n_objects < 0 || d->n_triangles < 0 || d->n_textures < 0 || (d->n_objects && !d->objects) ||
@@ -1964,7 +2259,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     std::vector<int32_t> prim_obj, prim_tri, by_kind[3];
     std::vector<double4> prim_rec;
     bool any_ks = false;
-    double rmax = 0, extent = 0;
+    double rmax = 0, extent = 0, ks_abs_max = 0;
     for (int i = 0; i < d->n_objects; i++) {
         const rt355_object &o = d->objects[i];
         if (o.type != RT355_OBJ_PLANE && o.type != RT355_OBJ_SPHERE && o.type != RT355_OBJ_MESH)
@@ -1972,6 +2267,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         if (o.fresnel != 1)
             return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": fresnel != 1 (refraction, main.cpp:116-154, is not accelerated)");
         if (o.ks != 0) any_ks = true;
+        ks_abs_max = std::max(ks_abs_max, std::isfinite(o.ks) ? fabs(o.ks) : 1e300);
         if (o.texture_type != 0 && o.texture_type != 1)
             return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": texture_type 2/3 (solid / procedural) is not accelerated");
         if (o.texture_type == 1 && (o.tex0 < 0 || o.tex1 < 0 || o.tex0 >= d->n_textures || o.tex1 >= d->n_textures))
@@ -2058,7 +2354,12 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->tables.n_prims_pad = std::max(256, (sc->view.n_prims + 255) / 256 * 256);
     sc->has_tris = d->n_triangles > 0;
     sc->reflective = any_ks;
+    sc->ks_abs_max = ks_abs_max;
     sc->rmax = rmax; sc->extent = extent;
+    if (any_ks && sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri))) {
+        rt355_scene_destroy(sc);
+        return rc;
+    }
     HIP_TRY(hipEventCreate(&sc->ev_begin));
     HIP_TRY(hipEventCreate(&sc->ev_end));
     void *ctr = nullptr;
@@ -2083,7 +2384,7 @@ static void free_tables(rt355_scene *sc) {
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
-                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank};
+                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
     w = Work{};
@@ -2226,11 +2527,31 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     f.grid_w = (int32_t)grid_w; f.grid_h = (int32_t)grid_h;
     f.tiles_x = (f.grid_w + TILE_W - 1) / TILE_W; f.tiles_y = (f.grid_h + TILE_H - 1) / TILE_H;
     f.n_rays = (uint32_t)n_rays64;
+    f.level = -1;
     const int nl = shader->n_lights;
     const int slots = slots_for(f.n_rays, nl);
     const int n_groups = (nl + slots - 1) / slots;
-    int rc = ensure_work(sc, f.n_rays, slots, 1 + 2 * n_groups, n_groups);
+    // Mirror rays on a searched scene: the frame is rendered level by level.  A chain goes on while the product
+    // of the ks it met is >= 0.05 and it has at most three mirror rays (main.cpp:27-28,103), so the largest |ks|
+    // of the scene bounds the number of levels.
+    const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
+    int extra_levels = 0;
+    if (can_search && sc->reflective && opts->shading == RT355_SHADING_LIGHTS) {
+        double k = 1.0;
+        while (extra_levels < 3 && (k *= sc->ks_abs_max) >= 0.05) extra_levels++;
+    }
+    const bool levels = extra_levels > 0;
+    int rc = ensure_work(sc, f.n_rays, slots, (1 + 2 * n_groups) * (1 + extra_levels), (1 + n_groups) * (1 + extra_levels) - 1);
     if (rc) return rc;
+    if (levels && !sc->work.lvl_clr) {
+        const size_t cap = sc->work_rays;
+        Work &wk = sc->work;
+        HIP_TRY(hipMalloc((void **)&wk.lvl_clr, 4 * cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&wk.lvl_ks, 4 * cap * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&wk.ktotal, cap * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&wk.deepest, cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&wk.ray_d, 6 * cap * sizeof(double)));
+    }
 
     // lights -> device
     std::vector<DLight> hl(nl);
@@ -2255,14 +2576,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
 
     // bundle 0 = camera rays (common origin: the eye); bundle 1+k = shadow rays of light k (common
     // origin: the light position, or common direction for a directional light)
-    const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
     const bool gather = opts->shading != RT355_SHADING_LIGHTS;
     if (can_search && gather)
         return fail(RT355_ERR_UNSUPPORTED, "the gather shaders (shading2 / shading3, shader.h:100-191) are rendered only without a search so far: "
                                            "scenes of fewer than 64 primitives, or RT355_MODE_BRUTE");
-    if (can_search && sc->reflective)
-        return fail(RT355_ERR_UNSUPPORTED, "objects with ks != 0 (reflection rays, main.cpp:93-112) are rendered only without a search so far: "
-                                           "scenes of fewer than 64 primitives, or RT355_MODE_BRUTE");
+    if (levels && !sc->has_general) return fail(RT355_ERR_ARG, "internal: the scene table for mirror rays is missing");
     std::vector<Bundle> bundles(2 + nl);
     for (auto &b : bundles) memset(&b, 0, sizeof b);
     if (can_search) {
@@ -2430,36 +2748,64 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             hipLaunchKernelGGL(k_render_direct<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
     }
-    if (bundles[0].kind) {
-        // camera rays: workspace slot 0, the last table slot (so that the lights' tables survive the frame)
-        Slots eye{};
-        eye.count = 1;
-        eye.table[0] = sc->table_slots - 1;
-        hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, w.ray32);
-        Group eye_group;
-        memset(&eye_group, 0, sizeof eye_group);
-        eye_group.count = 1; eye_group.b[0] = bundles[0];
-        TableMap eye_map{};
-        eye_map.slot[0] = sc->table_slots - 1;
-        if ((rc = build_tables(eye_group, eye_map))) return rc;
-        if ((rc = launch_search(1, eye, nullptr, nullptr, 0))) return rc;
-    }
-    Group cur = group_of(0);
+    int resolves = 0;
+    // one level of the frame: the search of its rays (camera rays: the eye's tables; mirror rays: the scene table),
+    // the fp64 closest hit and hit record, then the lights group by group
+    auto run_level = [&](int L) -> int {
+        Frame fl = f;
+        fl.level = levels ? L : -1;
+        if (L == 0) {
+            if (bundles[0].kind) {
+                // camera rays: workspace slot 0, the last table slot (so that the lights' tables survive the frame)
+                Slots eye{};
+                eye.count = 1;
+                eye.table[0] = sc->table_slots - 1;
+                hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, w.ray32);
+                Group eye_group;
+                memset(&eye_group, 0, sizeof eye_group);
+                eye_group.count = 1; eye_group.b[0] = bundles[0];
+                TableMap eye_map{};
+                eye_map.slot[0] = sc->table_slots - 1;
+                int rc1 = build_tables(eye_group, eye_map);
+                if (rc1) return rc1;
+                if ((rc1 = launch_search(1, eye, nullptr, nullptr, 0))) return rc1;
+            }
+        } else {
+            HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
+            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, w.ray_d, w.deepest,
+                               (uint32_t)L, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
+            HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
+            sc->launch_choice.push_back({-1, 0});
+            launches++;
+        }
+        Group cur = group_of(0);
+        int rc1 = clear_bins(cur);
+        if (rc1) return rc1;
+        HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
+        hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w,
+                           (L == 0 && !bundles[0].kind) ? 1 : 0, cur, pix);
+        HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
+        resolves++;
+        for (int j = 0; j < n_groups; j++) {
+            if ((rc1 = search_group(cur))) return rc1;
+            Group next = group_of(j + 1);
+            if ((rc1 = clear_bins(next))) return rc1;
+            HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
+            hipLaunchKernelGGL(k_shade_group, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
+            HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
+            resolves++;
+            cur = next;
+        }
+        return RT355_OK;
+    };
     if (can_search) {
-        if ((rc = clear_bins(cur))) return rc;
-        HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
-        hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w,
-                           bundles[0].kind ? 0 : 1, cur, pix);
-        HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
-    }
-    for (int j = 0; can_search && j < n_groups; j++) {
-        if ((rc = search_group(cur))) return rc;
-        Group next = group_of(j + 1);
-        if ((rc = clear_bins(next))) return rc;
-        HIP_TRY(hipEventRecord(sc->ev_resolve[2 + 2 * j], st));
-        hipLaunchKernelGGL(k_shade_group, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, f, w, cur, next, pix);
-        HIP_TRY(hipEventRecord(sc->ev_resolve[3 + 2 * j], st));
-        cur = next;
+        if ((rc = run_level(0))) return rc;
+        for (int L = 0; L < extra_levels; L++) {
+            hipLaunchKernelGGL(k_reflect_rays, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, dc, f, w, L);
+            if ((rc = run_level(L + 1))) return rc;
+        }
+        if (levels) hipLaunchKernelGGL(k_fold_levels, dim3(per_ray_blocks), dim3(256), 0, st, f, w, pix);
     }
     if (f.alias > 0)
         hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
@@ -2471,7 +2817,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     sc->pending_primary = (uint64_t)f.grid_w * (uint64_t)f.grid_h;
     sc->pending_nprims = sc->view.n_prims;
     sc->search_launches = launches;
-    sc->resolve_launches = can_search ? 1 + n_groups : 1;
+    sc->resolve_launches = can_search ? resolves : 1;
     return RT355_OK;
 }
 

@@ -45,12 +45,6 @@ def test_small_cases_vs_golden(api, golden_dir, name, mode):
     gold = np.load(os.path.join(golden_dir, f"frame_{name}.npy"))
     sc, sh, cam, w, h = S.small_case(name)
     r = api.Renderer(sc)
-    if mode != B.MODE_BRUTE and sc.n_primitives >= 64 and any(float(o["ks"]) != 0 for o in sc.objects):
-        # reflection rays have no search yet: refused, with the way out named
-        with pytest.raises(api.Rt355Error, match="RT355_MODE_BRUTE"):
-            r.render(cam, sh, w, h, mode=mode)
-        r.close()
-        return
     frame, st = r.render(cam, sh, w, h, mode=mode)
     r.close()
     _compare(frame, gold, exact=(name != "textured"))
@@ -62,13 +56,58 @@ def test_ray_counts_match_checker(api, oracle, name):
     sc, sh, cam, w, h = S.small_case(name)
     _, want = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=4)
     r = api.Renderer(sc)
-    _, st = r.render(cam, sh, w, h, mode=B.MODE_BRUTE if name.startswith("mirrors") else B.MODE_PACKET)
+    _, st = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
     r.close()
     assert st["primary_rays"] == want["primary_rays"]
     assert st["shadow_rays"] == want["shadow_rays"]
     assert st["secondary_rays"] == want["secondary_rays"]
     assert (st["secondary_rays"] > 0) == name.startswith("mirrors")
     assert st["overflow_rays"] == 0
+
+
+def _mirror_spheres(n, seed, n_lights):
+    """Random spheres over a mirror floor; every third sphere reflects, a few of them almost perfectly."""
+    sc = S.spheres_scene(n, seed=seed)
+    for i, o in enumerate(sc.objects):
+        if o["type"] == B.OBJ_PLANE:
+            o["ks"] = 0.4
+        elif i % 3 == 0:
+            o["ks"] = 0.9 if i % 9 == 0 else 0.5
+    return sc, S.Shader(S.ring_lights(n_lights), 0x101010, 0xDDDDDD, 0x202020)
+
+
+@pytest.mark.parametrize("mode", [B.MODE_PACKET, B.MODE_ALLPAIRS])
+def test_mirror_rays_on_searched_scenes(api, oracle, mode):
+    """Reflection (ks != 0, main.cpp:93-112) where the closest hits are searched: the mirror rays of each level go
+    through the scene table (k_search_general), their hits are shaded by the same light groups, and the levels are
+    folded back.  Frames, mirror-ray and shadow-ray counts equal the CPU checker's; the mesh case also against the
+    frame the reference's own classes produced (fixture)."""
+    for n, seed, nl, (w, h) in ((300, 91, 2, (160, 120)), (1500, 92, 3, (121, 91)), (64, 93, 9, (80, 60))):
+        sc, sh = _mirror_spheres(n, seed, nl)
+        cam = S.default_camera(w, h)
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+        r = api.Renderer(sc)
+        got, st = r.render(cam, sh, w, h, mode=mode)
+        brute, bst = r.render(cam, sh, w, h, mode=B.MODE_BRUTE)
+        r.close()
+        _compare(got, want)
+        _compare(brute, want)
+        assert st["secondary_rays"] == wst["secondary_rays"] == bst["secondary_rays"] > w * h // 20
+        assert st["shadow_rays"] == wst["shadow_rays"]
+    # supersampled, and slab by slab
+    sc, sh = _mirror_spheres(200, 94, 2)
+    w, h = 67, 45
+    cam = S.default_camera(w, h)
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=2, seed=5), threads=0)
+    r = api.Renderer(sc)
+    got, st = r.render(cam, sh, w, h, alias=2, seed=5, mode=mode)
+    _compare(got, want)
+    assert st["secondary_rays"] == wst["secondary_rays"]
+    parts = np.zeros_like(want)
+    for y0, y1 in ((0, 20), (20, h)):
+        r.render(cam, sh, w, h, alias=2, seed=5, mode=mode, row_begin=y0, row_end=y1, out=parts)
+    r.close()
+    assert np.array_equal(parts, want)
 
 
 def test_mirrors_supersampled(api, oracle):
