@@ -54,6 +54,16 @@ def build_workload(name: str):
     if name == "mesh100k_2lights_4k":
         w, h = 3840, 2160
         return S.mesh_scene(100_000, seed=356), S.mesh_shader(), S.default_camera(w, h), w, h
+    if name == "spheres10k_mirrors_8lights_4k":
+        # the spheres scene with a reflecting floor (ks 0.4) and every third sphere a mirror (ks 0.5, every ninth 0.9)
+        w, h = 3840, 2160
+        sc = S.spheres_scene(10000, seed=355)
+        for i, o in enumerate(sc.objects):
+            if i == 0:
+                o["ks"] = 0.4
+            elif i % 3 == 0:
+                o["ks"] = 0.9 if i % 9 == 0 else 0.5
+        return sc, S.spheres_shader(8), S.default_camera(w, h), w, h
     if name == "mesh1m_2lights_8k":
         w, h = 7680, 4320
         return S.mesh_scene(1_000_000, seed=356), S.mesh_shader(), S.default_camera(w, h), w, h
@@ -113,7 +123,7 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None
     t0 = time.perf_counter()
     _, st = O.render(p, cam, shader, B.opts(w, h, shading=shading), threads=threads, stride=stride, dirs=dirs)
     dt = time.perf_counter() - t0
-    count = lambda q: q["primary_rays"] + q["shadow_rays"] + q["gather_rays"]
+    count = lambda q: q["primary_rays"] + q["shadow_rays"] + q["gather_rays"] + q["secondary_rays"]
     rays = count(st)
     out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
@@ -238,7 +248,7 @@ def measure(name, args, ctx, headline):
     _, stats = run_frames(r, cam, shader, o, fb, stream, args.steps, gather)
     barrier()
     dt = time.perf_counter() - t0
-    rays_step = float(stats["primary_rays"] + stats["shadow_rays"] + stats["gather_rays"])
+    rays_step = float(stats["primary_rays"] + stats["shadow_rays"] + stats["gather_rays"] + stats["secondary_rays"])
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -273,7 +283,7 @@ def measure(name, args, ctx, headline):
            "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives,
                       "lights": len(shader.lights), "alias": 0, "shard": args.shard, "search": args.mode,
                       "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"],
-                                         "gather": stats["gather_rays"]},
+                                         "gather": stats["gather_rays"], "mirror": stats["secondary_rays"]},
                       "shading": {0: "Shader::shading", 1: "Shader::shading2", 2: "Shader::shading3"}[shading],
                       "gather_directions": 0 if dirs is None else len(dirs),
                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
@@ -294,7 +304,14 @@ def measure(name, args, ctx, headline):
                 "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_frame": launches // K,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": bytes_frame}
 
-    if not searched:
+    if stats["secondary_rays"] > 0 and searched:
+        # a frame rendered level by level: the launches of all levels are summed in kernel_time (search includes
+        # k_search_general, resolve_primary is level 0's, shade the rest); the per-kernel byte models below describe
+        # one level and are not applied
+        out["roofline"] = {"bound": "hbm", "kernel": "levels", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": None, "traffic": None,
+                           "note": "multi-level frame: see profiles/ for the per-kernel trace"}
+    elif not searched:
         # k_render_direct: the reference's own algorithm (every primitive tested for the camera ray and for every
         # shadow ray, fp64), one thread per pixel.  Priced as the reference-formula flops of those tests against
         # the FP32 vector peak; the shading of each hit (normalisations, x^25, 8-bit colour arithmetic), which
@@ -327,7 +344,7 @@ def measure(name, args, ctx, headline):
         out["roofline"] = rooflines[dominant]
         out["roofline_other_kernels"] = {k: v for k, v in rooflines.items() if k != dominant}
     for rf in [out["roofline"], *out.get("roofline_other_kernels", {}).values()]:
-        t = measured_traffic(name, rf["kernel"]) if args.mode == "packet" else None
+        t = measured_traffic(name, rf["kernel"]) if (args.mode == "packet" and rf.get("frac") is not None) else None
         if t:
             rf["traffic"] = t["bytes"]
             rf["traffic_detail"] = t
@@ -357,7 +374,7 @@ def measure(name, args, ctx, headline):
 
 
 HEADLINE = "default_4k"
-OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "default_bleed162_4k"]
+OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "default_bleed162_4k", "spheres10k_mirrors_8lights_4k"]
 
 
 def main():

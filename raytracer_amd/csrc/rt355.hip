@@ -1200,10 +1200,12 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
 struct GeneralTable {
     const float4 *prim;      // [n_prims_pad] centre, radius (rounded up); NaN = padding
     const uint32_t *prim_id; // [n_prims_pad] candidate id (primitive index | kind bits)
-    const float4 *chunk;     // [n_chunks_pad] bounding sphere of prim[64 j .. 64 j + 63]
+    const float4 *mini;      // [n_supers * 512] bounding sphere of prim[8 m .. 8 m + 7]
+    const float4 *chunk;     // [n_supers * 64] bounding sphere of prim[64 j .. 64 j + 63]
     const float4 *super;     // [n_supers] bounding sphere of chunk[64 k .. 64 k + 63]
     const uint32_t *plane_id;// [n_planes] candidate ids of the planes
     int32_t n_supers, n_planes;
+    float tight_rho, tight_theta; // a wave whose origin ball and cone are within these searches as one beam
 };
 struct Beam { float cx, cy, cz, rho, ax, ay, az, theta; };
 // may a ray of the beam hit the sphere q?  (NaN q: no)
@@ -1230,15 +1232,46 @@ __device__ __forceinline__ bool ray_meets(float ox, float oy, float oz, float ux
     const float reach = q.w + 3.8146973e-06f * (len + o_l1 + fabsf(q.x) + fabsf(q.y) + fabsf(q.z) + 1.0f); // 2^-18
     return dist2 <= reach * reach * 1.00001f && along >= -reach;
 }
+// The same search ray by ray: a lane walks the table's tree on its own (super -> chunks -> groups of 8 ->
+// primitives), one sphere test per turn of ONE loop, the position in the tree kept as (level, index) and moved
+// by index arithmetic -- down to the first child after a sphere the ray may hit, else on to the next sibling,
+// up when the siblings end.  For waves whose rays fan out (mirror rays off small spheres) the shared beam
+// holds most of the scene and the walk per ray is the cheaper one.
+__device__ __forceinline__ void walk_ray(const GeneralTable &t, float ox, float oy, float oz, float ux, float uy, float uz,
+                                         float o_l1, uint32_t rid, uint32_t n_rays, uint32_t *__restrict__ cand,
+                                         uint32_t &cnt, const Spill &sp, uint32_t &n_pairs) {
+    // levels: 0 super, 1 chunk (64 per super), 2 group of 8 (8 per chunk), 3 primitive (8 per group)
+    int lvl = 0;
+    uint32_t idx = 0;
+    while (idx < (uint32_t)t.n_supers || lvl > 0) {
+        const float4 q = lvl == 0 ? t.super[idx] : (lvl == 1 ? t.chunk[idx] : (lvl == 2 ? t.mini[idx] : t.prim[idx]));
+        const bool meets = ray_meets(ox, oy, oz, ux, uy, uz, o_l1, q); // NaN padding: no
+        n_pairs++;
+        if (meets && lvl < 3) { // down to the first child
+            idx = idx << (lvl == 0 ? 6 : 3);
+            lvl++;
+            continue;
+        }
+        if (meets) append_id(t.prim_id[idx], rid, n_rays, cand, cnt, sp);
+        idx++; // next sibling; past the last one, up to the parent's next sibling
+        while (lvl > 0 && (idx & (lvl == 1 ? 63u : 7u)) == 0) {
+            idx >>= (lvl == 1 ? 6 : 3);
+            lvl--;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const double *__restrict__ ray_d,
-                                                        const uint32_t *__restrict__ deepest, uint32_t level,
-                                                        uint32_t n_rays, uint32_t *__restrict__ cand,
-                                                        uint32_t *__restrict__ cand_cnt, Spill sp,
-                                                        unsigned long long *__restrict__ counters) {
-    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // n_rays is a multiple of the block size
+                                                        const uint32_t *__restrict__ list,
+                                                        const uint32_t *__restrict__ n_listed, uint32_t n_rays,
+                                                        uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_cnt,
+                                                        Spill sp, unsigned long long *__restrict__ counters) {
+    // the rays of this level, compacted in tile order (k_scatter_active): 64 neighbours on screen per wave
+    const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const size_t n = n_rays;
-    bool active = deepest[rid] == level;
+    const bool active = at < *n_listed;
+    const uint32_t rid = active ? list[at] : 0u;
     float ox = 0, oy = 0, oz = 0, ux = 0, uy = 0, uz = 0;
     bool odd = false; // a ray the beam cannot hold (no direction, not finite): left to the fp64 walk
     if (active) {
@@ -1270,7 +1303,9 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
         const float o_l1 = fabsf(ox) + fabsf(oy) + fabsf(oz);
         if (in_beam)
             for (int p = 0; p < t.n_planes; p++) append_id(t.plane_id[p], rid, n_rays, cand, cnt, sp);
-        for (int s0 = 0; s0 < t.n_supers; s0 += 64) {
+        const bool tight = b.rho <= t.tight_rho && b.theta <= t.tight_theta; // uniform
+        if (!tight && in_beam) walk_ray(t, ox, oy, oz, ux, uy, uz, o_l1, rid, n_rays, cand, cnt, sp, n_pairs);
+        for (int s0 = 0; tight && s0 < t.n_supers; s0 += 64) {
             const bool meets_s = (s0 + lane < t.n_supers) && beam_meets(b, t.super[s0 + lane]);
             unsigned long long ms = __ballot(meets_s);
             while (ms) { // uniform
@@ -1296,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
             }
         }
     }
-    cand_cnt[rid] = (active && odd) ? CAND_UNSEARCHED : cnt;
+    if (active) cand_cnt[rid] = odd ? CAND_UNSEARCHED : cnt;
     wave_count(counters, 5, n_pairs);
 }
 
@@ -1825,9 +1860,14 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
     wave_count(w.counters, 7, n_gather);
 }
 
-__global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+// LEVELS: the frame is rendered level by level (mirror rays on a searched scene); compiled apart so that frames
+// without levels run the kernel they always ran.
+template <bool LEVELS>
+__global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f_in, Work w,
                                                          int brute, Group first,
                                                          unsigned char *__restrict__ pixmap) {
+    Frame f = f_in;
+    if (!LEVELS) f.level = -1;
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_eval = 0, n_over = 0, n_hit = 0;
     bool got_hit = false;
@@ -1841,7 +1881,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         break;
     }
     Ray e;
-    if (f.level > 0) { // the mirror rays of level f.level (k_reflect_rays left them in ray_d); -2 = this chain has ended
+    if (LEVELS && f.level > 0) { // the mirror rays of level f.level (k_reflect_rays left them in ray_d); -2 = this chain has ended
         if (w.deepest[rid] != (uint32_t)f.level) { w.rec_obj[rid] = -2; break; }
         const size_t n = f.n_rays;
         e.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
@@ -1889,6 +1929,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
 __global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, Frame f, Work w, int level) {
     const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_secondary = 0;
+    float4 rec = nan4(); // slot 0's fp32 record: the direction of a mirror ray, NaN where there is none
     do {
     if (rid >= f.n_rays) break;
     int x, y;
@@ -1918,8 +1959,12 @@ __global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, 
     w.ray_d[0 * n + rid] = r.pe.x; w.ray_d[1 * n + rid] = r.pe.y; w.ray_d[2 * n + rid] = r.pe.z;
     w.ray_d[3 * n + rid] = r.npe.x; w.ray_d[4 * n + rid] = r.npe.y; w.ray_d[5 * n + rid] = r.npe.z;
     w.deepest[rid] = (uint32_t)level + 1u;
+    // (a direction that is not a number still marks the ray as there: the search hands it to the fp64 walk)
+    rec = make_float4((float)r.npe.x, (float)r.npe.y, (float)r.npe.z, 0.f);
+    if (!(rec.x == rec.x)) rec.x = 0.f;
     n_secondary = 1;
     } while (0);
+    if (rid < f.n_rays) w.ray32[rid] = rec;
     wave_count(w.counters, 6, n_secondary);
 }
 
@@ -2233,7 +2278,9 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     std::vector<float4> prim_rows(n_supers * 4096, make_float4(nanf_, nanf_, nanf_, nanf_)), chunk_rows(n_supers * 64, make_float4(nanf_, nanf_, nanf_, nanf_)), super_rows(n_supers);
     std::vector<uint32_t> prim_ids(n_supers * 4096, 0u);
     std::vector<BoundSphere> chunks(n_chunks);
+    std::vector<float4> mini_rows(n_supers * 512, make_float4(nanf_, nanf_, nanf_, nanf_));
     for (size_t i = 0; i < sorted.size(); i++) { prim_rows[i] = to_row(sorted[i]); prim_ids[i] = sorted[i].id; }
+    for (size_t m = 0; m * 8 < sorted.size(); m++) mini_rows[m] = to_row(enclose(&sorted[m * 8], std::min<size_t>(8, sorted.size() - m * 8)));
     for (size_t j = 0; j < n_chunks; j++) {
         chunks[j] = enclose(&sorted[j * 64], std::min<size_t>(64, sorted.size() - j * 64));
         chunk_rows[j] = to_row(chunks[j]);
@@ -2242,9 +2289,20 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     GeneralTable &g = sc->general;
     int rc;
     if ((rc = upload(sc, prim_rows, &g.prim)) || (rc = upload(sc, prim_ids, &g.prim_id)) || (rc = upload(sc, chunk_rows, &g.chunk)) ||
+        (rc = upload(sc, mini_rows, &g.mini)) ||
         (rc = upload(sc, super_rows, &g.super)) || (rc = upload(sc, planes, &g.plane_id)))
         return rc;
     g.n_supers = (int32_t)n_supers; g.n_planes = (int32_t)planes.size();
+    double mean_group = 0; // mean radius of the groups of 8: the scale below which a beam is "thin"
+    size_t n_groups8 = 0;
+    for (size_t m = 0; m * 8 < sorted.size(); m++, n_groups8++) mean_group += mini_rows[m].w;
+    g.tight_rho = n_groups8 ? (float)(mean_group / (double)n_groups8) : 0.0f;
+    g.tight_rho *= 2.0f;
+    g.tight_theta = 0.3f;
+    if (const char *e = getenv("RT355_GENERAL_TIGHT")) { // "rho_factor,theta": tuning aid
+        double a = 1, b = 0.2;
+        if (sscanf(e, "%lf,%lf", &a, &b) == 2) { g.tight_rho *= (float)a; g.tight_theta = (float)b; }
+    }
     sc->has_general = true;
     return RT355_OK;
 }
@@ -2773,8 +2831,13 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         } else {
             HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
             HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
-            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, w.ray_d, w.deepest,
-                               (uint32_t)L, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
+            Slots one{}; // the mirror rays of this level, compacted (slot 0's lists)
+            one.count = 1;
+            hipLaunchKernelGGL(k_count_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, one);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, one);
+            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
+            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, w.ray_d, w.active_rid,
+                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
             HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
             sc->launch_choice.push_back({-1, 0});
             launches++;
@@ -2783,8 +2846,12 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         int rc1 = clear_bins(cur);
         if (rc1) return rc1;
         HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
-        hipLaunchKernelGGL(k_resolve_primary, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w,
-                           (L == 0 && !bundles[0].kind) ? 1 : 0, cur, pix);
+        if (levels)
+            hipLaunchKernelGGL(k_resolve_primary<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w,
+                               (L == 0 && !bundles[0].kind) ? 1 : 0, cur, pix);
+        else
+            hipLaunchKernelGGL(k_resolve_primary<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w,
+                               (L == 0 && !bundles[0].kind) ? 1 : 0, cur, pix);
         HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
         resolves++;
         for (int j = 0; j < n_groups; j++) {
