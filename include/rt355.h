@@ -48,7 +48,7 @@ typedef struct rt355_object {
                          n1 = n0 x ni as the Plane ctor does (:57); this field is ignored. */
     double n2[3];     /* Sphere::n2 (:105)                                                   */
     double radius;    /* Sphere::radius (:102)                                               */
-    double ks;        /* AnyObject::ks (:22); != 0 is rendered only without a search (see rt355_render) */
+    double ks;        /* AnyObject::ks (:22): reflection coefficient (main.cpp:93-112)                       */
     double fresnel;   /* AnyObject::fresnel (:21); must be 1 (no refraction yet)             */
     double ior;       /* AnyObject::IOR (:20); carried, unused while fresnel == 1            */
     int32_t type;     /* RT355_OBJ_*                                                         */
