@@ -428,6 +428,37 @@ def test_random_scenes_search_is_conservative(api, oracle, seed):
     assert pst["exact_tests"] == st["exact_tests"]
 
 
+@pytest.mark.parametrize("seed", range(10, 22))
+def test_random_scenes_with_mirrors(api, oracle, seed):
+    """The same random scenes with random reflection coefficients (object 0 included, so that rays that miss go
+    on, main.cpp:94), overlapping spheres, mirror meshes, eyes inside spheres: the search of the mirror rays
+    must lose nothing either.  Every third seed is scaled up a thousandfold and moved far from the origin, where
+    fp32 has few digits left for the geometry."""
+    sc, sh, cam, w, h = _random_case(seed)
+    rng = S.SplitMix64(777 + seed)
+    for i, o in enumerate(sc.objects):
+        u = rng.uniform()
+        if i == 0 or u < 0.4:
+            o["ks"] = (0.3, 0.55, 0.8, 0.97, 1.0)[int(rng.uniform(0, 5))]
+    if seed % 3 == 0:
+        k, shift = 1000.0, np.array([3.0e5, -2.0e5, 1.0e5])
+        for o in sc.objects:
+            o["p"] = o["p"] * k + shift
+            o["radius"] = o["radius"] * k
+        sc.triangles = [np.concatenate([(t[:, :9].reshape(-1, 3, 3) * k + shift).reshape(-1, 9), t[:, 9:]], axis=1) for t in sc.triangles]
+        for l in sh.lights:
+            l["position"] = l["position"] * k + shift
+        cam.p_eye[:] = list(np.array(list(cam.p_eye)) * k + shift)
+        cam.dist *= k; cam.s_x *= k; cam.s_y *= k
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    r = api.Renderer(sc)
+    got, st = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
+    r.close()
+    _compare(got, want)
+    assert st["secondary_rays"] == wst["secondary_rays"] > 0
+    assert st["shadow_rays"] == wst["shadow_rays"]
+
+
 @pytest.mark.gpu
 def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
     """CalcSubPixel2 with shading3 / shading2 (main.cpp:163-209, shader.h:100-191), HEAD's renderer: frames
