@@ -2260,19 +2260,46 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
         for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.c[a]); hi[a] = std::max(hi[a], b.c[a]); }
         prims.push_back(b);
     }
-    std::vector<std::pair<uint64_t, uint32_t>> order(prims.size());
-    for (size_t i = 0; i < prims.size(); i++) {
-        uint64_t code = 0;
-        for (int a = 0; a < 3; a++) {
-            const double span = hi[a] - lo[a];
-            const double u = span > 0 ? (prims[i].c[a] - lo[a]) / span : 0.0;
-            code |= spread21((uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0))) << a;
-        }
-        order[i] = {code, (uint32_t)i};
-    }
-    std::sort(order.begin(), order.end());
+    // Order: a balanced k-d split of the centres whose cuts fall on the group boundaries of the table -- a range
+    // longer than 4096 is cut at the multiple of 4096 nearest its middle, then at multiples of 64, then of 8 --
+    // along the axis the range extends furthest in.  Every group of 8, 64 or 4096 consecutive primitives is
+    // then a box-shaped cell of the split.  (RT355_GENERAL_ORDER=morton keeps the plain Morton order.)
     std::vector<BoundSphere> sorted(prims.size());
-    for (size_t i = 0; i < prims.size(); i++) sorted[i] = prims[order[i].second];
+    if (getenv("RT355_GENERAL_ORDER") && !strcmp(getenv("RT355_GENERAL_ORDER"), "morton")) {
+        std::vector<std::pair<uint64_t, uint32_t>> order(prims.size());
+        for (size_t i = 0; i < prims.size(); i++) {
+            uint64_t code = 0;
+            for (int a = 0; a < 3; a++) {
+                const double span = hi[a] - lo[a];
+                const double u = span > 0 ? (prims[i].c[a] - lo[a]) / span : 0.0;
+                code |= spread21((uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0))) << a;
+            }
+            order[i] = {code, (uint32_t)i};
+        }
+        std::sort(order.begin(), order.end());
+        for (size_t i = 0; i < prims.size(); i++) sorted[i] = prims[order[i].second];
+    } else {
+        sorted = prims;
+        std::vector<std::pair<size_t, size_t>> todo{{0, sorted.size()}};
+        while (!todo.empty()) {
+            const size_t b = todo.back().first, e = todo.back().second;
+            todo.pop_back();
+            const size_t len = e - b;
+            if (len <= 8) continue;
+            const size_t g = len > 4096 ? 4096 : (len > 64 ? 64 : 8);
+            size_t mid = b + std::max<size_t>(1, (len / 2 + g / 2) / g) * g; // b is a multiple of g by construction
+            if (mid >= e) mid = b + (len - 1) / g * g;
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+            for (size_t i = b; i < e; i++)
+                for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], sorted[i].c[a]); mx[a] = std::max(mx[a], sorted[i].c[a]); }
+            int axis = 0;
+            for (int a = 1; a < 3; a++) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+            std::nth_element(sorted.begin() + b, sorted.begin() + mid, sorted.begin() + e,
+                             [axis](const BoundSphere &p, const BoundSphere &q) { return p.c[axis] < q.c[axis]; });
+            todo.push_back({b, mid});
+            todo.push_back({mid, e});
+        }
+    }
     const size_t n_chunks = (sorted.size() + 63) / 64, n_supers = (n_chunks + 63) / 64;
     const float nanf_ = nanf("");
     std::vector<float4> prim_rows(n_supers * 4096, make_float4(nanf_, nanf_, nanf_, nanf_)), chunk_rows(n_supers * 64, make_float4(nanf_, nanf_, nanf_, nanf_)), super_rows(n_supers);
