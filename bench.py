@@ -51,7 +51,7 @@ def build_workload(name: str):
     if name in ("default_4k", "default_bleed162_4k"):
         w, h = 3840, 2160
         return S.default_scene(), S.default_shader(1), S.default_camera(w, h), w, h
-    if name == "mesh100k_2lights_4k":
+    if name in ("mesh100k_2lights_4k", "mesh100k_bleed42_4k"):
         w, h = 3840, 2160
         return S.mesh_scene(100_000, seed=356), S.mesh_shader(), S.default_camera(w, h), w, h
     if name == "spheres10k_mirrors_8lights_4k":
@@ -79,6 +79,8 @@ def gather_of(name: str):
     from raytracer_amd import binding as B
     if name == "default_bleed162_4k":
         return B.SHADING_BLEED, B.geodesic(B.icosphere(2))
+    if name == "mesh100k_bleed42_4k":  # a searched scene: the gather rays go through the scene table, one direction per pass
+        return B.SHADING_BLEED, B.geodesic(B.icosphere(1))
     return B.SHADING_LIGHTS, None
 
 
@@ -304,7 +306,7 @@ def measure(name, args, ctx, headline):
                 "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_frame": launches // K,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_frame": bytes_frame}
 
-    if stats["secondary_rays"] > 0 and searched:
+    if (stats["secondary_rays"] > 0 or stats["gather_rays"] > 0) and searched:
         # a frame rendered level by level: the launches of all levels are summed in kernel_time (search includes
         # k_search_general, resolve_primary is level 0's, shade the rest); the per-kernel byte models below describe
         # one level and are not applied

@@ -1345,6 +1345,8 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
 // hit at t = 0.  Such a mesh is only known once all candidates were seen, so if the winner belongs to it
 // the candidates are walked once more without it; two such meshes send the ray to the ordered walk over
 // everything (as does a ray whose candidates did not fit its own slots AND the bundle's spill list).
+// POSITIVE: the gather loops' rule, an object's hit counts only with t > 0 (shader.h:130,176).
+template <bool POSITIVE = false>
 __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                             uint32_t n_rays, const uint32_t *__restrict__ cand,
                                             const uint32_t *__restrict__ cand_cnt, const Spill &sp, Closest &c,
@@ -1386,7 +1388,7 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
                 } else {
                     t = plane_t(s.objects[__double2loint(rec.x)], e);
                 }
-                if (t >= 0 && (t < bt || (t == bt && prim < bprim))) { bt = t; bprim = prim; bobj = obj; }
+                if ((POSITIVE ? t > 0 : t >= 0) && (t < bt || (t == bt && prim < bprim))) { bt = t; bprim = prim; bobj = obj; }
             };
             // CAND_BATCH candidates at a time: first their ids, then their 32-byte records (independent
             // loads, all in flight together), then the tests
@@ -1413,7 +1415,7 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
     }
     if (brute) {
         c.init();
-        closest_by_kind<false, false>(s, e, c.t_best, c.prim_best);
+        closest_by_kind<POSITIVE, false>(s, e, c.t_best, c.prim_best);
         n = (uint32_t)s.n_prims;
     }
     evaluated += n;
@@ -1858,6 +1860,106 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 7, n_gather);
+}
+
+// ---- the gather shaders on searched scenes ----------------------------------------------------------------
+// The camera rays' hits are found as usual (k_resolve_primary writes the hit records), then the direction
+// set is taken ONE direction per pass: k_gather_emit turns it by each hit's two angles and keeps the hits it
+// passes the normal test for, the live rays are compacted and searched in the scene table (k_search_general),
+// k_gather_resolve takes their closest hit with t > 0 on the candidates and adds to the hit's counts and colour
+// sums, and after the last direction k_gather_finish blends the pixel.  The per-hit state lives in the arrays
+// the levels of mirror rays use: lvl_ks[0..3] = sin and cos of the two angles, lvl_clr[0] = cnt,
+// lvl_clr[1..3] = the colour sums.
+__global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w) {
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rid >= f.n_rays || w.rec_obj[rid] < 0) return;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    int px = x, py = y + f.row_begin, sample = 0; // the sub-sample this hit belongs to keys the two random numbers
+    if (f.alias > 0) {
+        px = x / f.alias; py = y / f.alias + f.row_begin;
+        sample = (y % f.alias) * f.alias + x % f.alias;
+    }
+    const double theta1 = rt355x_rotation(f.seed, px, py, sample, 0) * 2 * RT_PI; // shader.h:106-109,149-152
+    const double theta2 = rt355x_rotation(f.seed, px, py, sample, 1) * 2 * RT_PI;
+    double s1, c1, s2, c2;
+    sincos_rounded(theta1, &s1, &c1);
+    sincos_rounded(theta2, &s2, &c2);
+    const size_t n = f.n_rays;
+    w.lvl_ks[0 * n + rid] = s1; w.lvl_ks[1 * n + rid] = c1; w.lvl_ks[2 * n + rid] = s2; w.lvl_ks[3 * n + rid] = c2;
+    w.lvl_clr[0 * n + rid] = 0u; w.lvl_clr[1 * n + rid] = 0u; w.lvl_clr[2 * n + rid] = 0u; w.lvl_clr[3 * n + rid] = 0u;
+}
+__global__ __launch_bounds__(256) void k_gather_emit(Frame f, Work w, Gather ga, int i) {
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_gather = 0;
+    float4 rec = nan4();
+    if (rid < f.n_rays && w.rec_obj[rid] >= 0) {
+        const size_t n = f.n_rays;
+        const double s1 = w.lvl_ks[0 * n + rid], c1 = w.lvl_ks[1 * n + rid], s2 = w.lvl_ks[2 * n + rid], c2 = w.lvl_ks[3 * n + rid];
+        const double gx = ga.dirs[3 * i], gy = ga.dirs[3 * i + 1], gz = ga.dirs[3 * i + 2];
+        const double x1 = c1 * gx - s1 * gy, y1 = s1 * gx + c1 * gy;                      // shader.h:115,160
+        const d3 ray = D3(x1, c2 * y1 - s2 * gz, s2 * y1 + c2 * gz);                      // :119,164
+        const d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+        if (!(dot(ray, nh) <= 0)) {                                                       // :122,167
+            const Ray vw = mkview(D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]), ray); // :127,173
+            w.ray_d[0 * n + rid] = vw.pe.x; w.ray_d[1 * n + rid] = vw.pe.y; w.ray_d[2 * n + rid] = vw.pe.z;
+            w.ray_d[3 * n + rid] = vw.npe.x; w.ray_d[4 * n + rid] = vw.npe.y; w.ray_d[5 * n + rid] = vw.npe.z;
+            rec = make_float4((float)vw.npe.x, (float)vw.npe.y, (float)vw.npe.z, 0.f);
+            if (!(rec.x == rec.x)) rec.x = 0.f; // not a number: still a ray; the search leaves it to the fp64 walk
+            n_gather = 1;
+        }
+    }
+    if (rid < f.n_rays) w.ray32[rid] = rec;
+    wave_count(w.counters, 7, n_gather);
+}
+template <bool BLEED>
+__global__ __launch_bounds__(256) void k_gather_resolve(SceneView s, Frame f, Work w, const uint32_t *__restrict__ list,
+                                                        const uint32_t *__restrict__ n_listed) {
+    const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_eval = 0, n_over = 0;
+    if (at < *n_listed) {
+        const uint32_t rid = list[at];
+        const size_t n = f.n_rays;
+        Ray vw;
+        vw.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
+        vw.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
+        Closest c;
+        closest_hit<true>(s, vw, false, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
+        if (BLEED) {
+            if (c.t_best < 100) {                                                         // shader.h:181-184
+                const uint32_t hc = s.objects[s.prim_obj[c.prim_best]].rgb;
+                w.lvl_clr[1 * n + rid] += cr(hc); w.lvl_clr[2 * n + rid] += cg(hc); w.lvl_clr[3 * n + rid] += cb(hc);
+                w.lvl_clr[0 * n + rid] += 2u;
+            }
+        } else if (c.prim_best >= 0) {                                                    // :130-133
+            w.lvl_clr[0 * n + rid] += 2u;
+        }
+    }
+    wave_count(w.counters, 1, n_eval);
+    wave_count(w.counters, 2, n_over);
+}
+template <bool BLEED>
+__global__ __launch_bounds__(256) void k_gather_finish(SceneView s, ShaderView sh, Frame f, Work w, Gather ga,
+                                                       unsigned char *__restrict__ pixmap) {
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rid >= f.n_rays) return;
+    const int obj = w.rec_obj[rid];
+    if (obj == -2) return;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    uint32_t clr = 0u; // main.cpp:167,204
+    if (obj >= 0) {
+        const size_t n = f.n_rays;
+        const uint32_t cnt = w.lvl_clr[0 * n + rid];
+        const double part = (double)(int)cnt * 1.0 / (double)ga.n;                         // shader.h:137,188
+        uint32_t other = sh.ambient;
+        if (BLEED) {
+            const double m = (double)(int)cnt;                                             // :187
+            other = RGB(q8((double)w.lvl_clr[1 * n + rid] / m), q8((double)w.lvl_clr[2 * n + rid] / m), q8((double)w.lvl_clr[3 * n + rid] / m));
+        }
+        clr = cadd(cmul(s.objects[obj].rgb, 1 - part), cmul(other, part));
+    }
+    store_pixel(pixmap, f, w, rid, x, y, clr);
 }
 
 // LEVELS: the frame is rendered level by level (mirror rays on a searched scene); compiled apart so that frames
@@ -2441,7 +2543,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->reflective = any_ks;
     sc->ks_abs_max = ks_abs_max;
     sc->rmax = rmax; sc->extent = extent;
-    if (any_ks && sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri))) {
+    if (sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri))) {
         rt355_scene_destroy(sc);
         return rc;
     }
@@ -2626,9 +2728,10 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         while (extra_levels < 3 && (k *= sc->ks_abs_max) >= 0.05) extra_levels++;
     }
     const bool levels = extra_levels > 0;
+    const bool gather_searched = can_search && opts->shading != RT355_SHADING_LIGHTS;
     int rc = ensure_work(sc, f.n_rays, slots, (1 + 2 * n_groups) * (1 + extra_levels), (1 + n_groups) * (1 + extra_levels) - 1);
     if (rc) return rc;
-    if (levels && !sc->work.lvl_clr) {
+    if ((levels || gather_searched) && !sc->work.lvl_clr) {
         const size_t cap = sc->work_rays;
         Work &wk = sc->work;
         HIP_TRY(hipMalloc((void **)&wk.lvl_clr, 4 * cap * sizeof(uint32_t)));
@@ -2662,9 +2765,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     // bundle 0 = camera rays (common origin: the eye); bundle 1+k = shadow rays of light k (common
     // origin: the light position, or common direction for a directional light)
     const bool gather = opts->shading != RT355_SHADING_LIGHTS;
-    if (can_search && gather)
-        return fail(RT355_ERR_UNSUPPORTED, "the gather shaders (shading2 / shading3, shader.h:100-191) are rendered only without a search so far: "
-                                           "scenes of fewer than 64 primitives, or RT355_MODE_BRUTE");
+    if (gather_searched && !sc->has_general) return fail(RT355_ERR_ARG, "internal: the scene table for gather rays is missing");
     if (levels && !sc->has_general) return fail(RT355_ERR_ARG, "internal: the scene table for mirror rays is missing");
     std::vector<Bundle> bundles(2 + nl);
     for (auto &b : bundles) memset(&b, 0, sizeof b);
@@ -2893,7 +2994,57 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         }
         return RT355_OK;
     };
-    if (can_search) {
+    if (gather_searched) {
+        // hits of the camera rays (no lights on this path: hit records only), then one pass per gather direction
+        ShaderView no_lights = sh;
+        no_lights.n_lights = 0;
+        Frame fl = f;
+        fl.level = 0;
+        if (bundles[0].kind) {
+            Slots eye{};
+            eye.count = 1;
+            eye.table[0] = sc->table_slots - 1;
+            hipLaunchKernelGGL(k_gen_primary, dim3(per_ray_blocks), dim3(256), 0, st, dc, f, w.ray32);
+            Group eye_group;
+            memset(&eye_group, 0, sizeof eye_group);
+            eye_group.count = 1; eye_group.b[0] = bundles[0];
+            TableMap eye_map{};
+            eye_map.slot[0] = sc->table_slots - 1;
+            if ((rc = build_tables(eye_group, eye_map))) return rc;
+            if ((rc = launch_search(1, eye, nullptr, nullptr, 0))) return rc;
+        }
+        Group none;
+        memset(&none, 0, sizeof none);
+        HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
+        hipLaunchKernelGGL(k_resolve_primary<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, no_lights, dc, fl, w,
+                           bundles[0].kind ? 0 : 1, none, pix);
+        HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
+        resolves = 1;
+        hipLaunchKernelGGL(k_gather_init, dim3(per_ray_blocks), dim3(256), 0, st, f, w);
+        const Gather ga{sc->d_dirs, sc->n_dirs};
+        const bool bleed = opts->shading == RT355_SHADING_BLEED;
+        Slots one{};
+        one.count = 1;
+        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
+        for (int i = 0; i < sc->n_dirs; i++) {
+            hipLaunchKernelGGL(k_gather_emit, dim3(per_ray_blocks), dim3(256), 0, st, f, w, ga, i);
+            hipLaunchKernelGGL(k_count_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, one);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, one);
+            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
+            HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, w.ray_d, w.active_rid,
+                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
+            if (bleed)
+                hipLaunchKernelGGL(k_gather_resolve<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.tile_count + n_tiles);
+            else
+                hipLaunchKernelGGL(k_gather_resolve<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.tile_count + n_tiles);
+        }
+        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st)); // all passes as one entry of the search times
+        sc->launch_choice.push_back({-1, 0});
+        launches++;
+        if (bleed) hipLaunchKernelGGL(k_gather_finish<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, f, w, ga, pix);
+        else hipLaunchKernelGGL(k_gather_finish<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, f, w, ga, pix);
+    } else if (can_search) {
         if ((rc = run_level(0))) return rc;
         for (int L = 0; L < extra_levels; L++) {
             hipLaunchKernelGGL(k_reflect_rays, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, dc, f, w, L);

@@ -472,10 +472,11 @@ def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
         cam = S.default_camera(w, h)
         r = api.Renderer(sc)
         r.set_directions(B.geodesic(B.icosphere(c["level"])))
-        got, st = r.render(cam, sh, w, h, alias=c["alias"], seed=c["seed"], shading=c["shading"], mode=B.MODE_BRUTE)
+        for mode in (B.MODE_BRUTE, B.MODE_PACKET):  # PACKET: the mesh cases search their gather rays in the scene table
+            got, st = r.render(cam, sh, w, h, alias=c["alias"], seed=c["seed"], shading=c["shading"], mode=mode)
+            _compare(got, np.load(os.path.join(golden_dir, c["file"])))
+            assert st["gather_rays"] > 0 and st["shadow_rays"] == 0
         r.close()
-        _compare(got, np.load(os.path.join(golden_dir, c["file"])))
-        assert st["gather_rays"] > 0 and st["shadow_rays"] == 0
     for name in ("default_2lights", "inside", "mesh", "spheres300", "empty_scene"):
         sc, sh, cam, w, h = S.small_case(name)
         w, h = (w // 2) | 1, (h // 2) | 1
@@ -485,16 +486,17 @@ def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
             dirs = B.geodesic(B.icosphere(level))
             r.set_directions(dirs)
             want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=9, shading=shading), threads=0, dirs=dirs)
-            got, st = r.render(cam, sh, w, h, alias=alias, seed=9, shading=shading, mode=B.MODE_BRUTE)
-            _compare(got, want)
-            assert st["gather_rays"] == wst["gather_rays"], (name, level, shading, alias)
+            for mode in (B.MODE_BRUTE, B.MODE_PACKET, B.MODE_ALLPAIRS):
+                got, st = r.render(cam, sh, w, h, alias=alias, seed=9, shading=shading, mode=mode)
+                _compare(got, want)
+                assert st["gather_rays"] == wst["gather_rays"], (name, level, shading, alias, mode)
         r.close()
 
 
 @pytest.mark.gpu
 def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle, monkeypatch):
     """A scene of a few objects renders the gather shaders in every mode (nothing is searched), slab by slab
-    as well; no direction set gives black hits; a searched scene is refused with a message that says why."""
+    as well; no direction set gives black hits, on a searched scene too."""
     sc, sh, cam, w, h = S.small_case("default_2lights")
     dirs = B.geodesic(B.icosphere(1))
     want, _ = oracle.render(sc.pack(), cam, sh, B.opts(w, h, seed=3, shading=B.SHADING_BLEED), threads=0, dirs=dirs)
@@ -522,9 +524,8 @@ def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle, monkeypatc
     r.close()
     big, bsh, bcam, bw, bh = S.small_case("spheres300")
     r = api.Renderer(big)
-    r.set_directions(dirs)
-    with pytest.raises(api.Rt355Error, match="gather"):
-        r.render(bcam, bsh, bw, bh, shading=B.SHADING_BLEED, mode=B.MODE_PACKET)
+    black, st = r.render(bcam, bsh, bw, bh, shading=B.SHADING_BLEED, mode=B.MODE_PACKET)
+    assert not black.any() and st["gather_rays"] == 0 and st["primary_hits"] > 0
     r.close()
 
 
