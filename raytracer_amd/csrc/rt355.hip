@@ -1200,6 +1200,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
 struct GeneralTable {
     const float4 *prim;      // [n_prims_pad] centre, radius (rounded up); NaN = padding
     const uint32_t *prim_id; // [n_prims_pad] candidate id (primitive index | kind bits)
+    const float4 *prim_n;    // [n_prims_pad] a triangle's unit normal and w = 1; zero for a sphere
     const float4 *mini;      // [n_supers * 512] bounding sphere of prim[8 m .. 8 m + 7]
     const float4 *chunk;     // [n_supers * 64] bounding sphere of prim[64 j .. 64 j + 63]
     const float4 *super;     // [n_supers] bounding sphere of chunk[64 k .. 64 k + 63]
@@ -1232,6 +1233,24 @@ __device__ __forceinline__ bool ray_meets(float ox, float oy, float oz, float ux
     const float reach = q.w + 3.8146973e-06f * (len + o_l1 + fabsf(q.x) + fabsf(q.y) + fabsf(q.z) + 1.0f); // 2^-18
     return dist2 <= reach * reach * 1.00001f && along >= -reach;
 }
+// For a triangle the bounding sphere is followed by its plane: Triangle::CalcIntersect misses when the normal
+// does not face the ray (anyobject.h:487-492), and where the ray meets the plane must lie inside the bounding
+// sphere (the centroid the sphere is centred on lies on the plane, so t = n . (c - o) / n . u).  A grazing ray
+// gets no opinion.
+__device__ __forceinline__ bool ray_meets_plane_of(float ox, float oy, float oz, float ux, float uy, float uz, float o_l1,
+                                                   const float4 &q, const float4 &nq) {
+    if (nq.w == 0.0f) return true;
+    const float den = nq.x * ux + nq.y * uy + nq.z * uz;
+    if (den > 1e-5f) return false;
+    if (den > -1e-2f) return true;
+    const float vx = q.x - ox, vy = q.y - oy, vz = q.z - oz;
+    const float t = (nq.x * vx + nq.y * vy + nq.z * vz) / den;
+    const float slack = 2.4414062e-04f * (fabsf(vx) + fabsf(vy) + fabsf(vz) + o_l1 + fabsf(q.x) + fabsf(q.y) + fabsf(q.z) + 1.0f); // 2^-12
+    if (!(t >= -slack)) return false;
+    const float px = t * ux - vx, py = t * uy - vy, pz = t * uz - vz;
+    const float reach = q.w + slack;
+    return px * px + py * py + pz * pz <= reach * reach;
+}
 // The same search ray by ray: a lane walks the table's tree on its own (super -> chunks -> groups of 8 ->
 // primitives), one sphere test per turn of ONE loop, the position in the tree kept as (level, index) and moved
 // by index arithmetic -- down to the first child after a sphere the ray may hit, else on to the next sibling,
@@ -1252,7 +1271,8 @@ __device__ __forceinline__ void walk_ray(const GeneralTable &t, float ox, float 
             lvl++;
             continue;
         }
-        if (meets) append_id(t.prim_id[idx], rid, n_rays, cand, cnt, sp);
+        if (meets && ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, q, t.prim_n[idx]))
+            append_id(t.prim_id[idx], rid, n_rays, cand, cnt, sp);
         idx++; // next sibling; past the last one, up to the parent's next sibling
         while (lvl > 0 && (idx & (lvl == 1 ? 63u : 7u)) == 0) {
             idx >>= (lvl == 1 ? 6 : 3);
@@ -1316,6 +1336,7 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
                     const size_t j = (size_t)k * 64 + (size_t)__builtin_ctzll(mc);
                     mc &= mc - 1;
                     const float4 q = t.prim[j * 64 + lane];
+                    const float4 qn = t.prim_n[j * 64 + lane];
                     const uint32_t qid = t.prim_id[j * 64 + lane];
                     unsigned long long mp = __ballot(beam_meets(b, q));
                     while (mp) {
@@ -1323,9 +1344,13 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
                         mp &= mp - 1;
                         float4 one;
                         one.x = lane_bcast(q.x, l); one.y = lane_bcast(q.y, l); one.z = lane_bcast(q.z, l); one.w = lane_bcast(q.w, l);
+                        float4 one_n;
+                        one_n.x = lane_bcast(qn.x, l); one_n.y = lane_bcast(qn.y, l); one_n.z = lane_bcast(qn.z, l); one_n.w = lane_bcast(qn.w, l);
                         const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)qid, l);
                         n_pairs += in_beam ? 1u : 0u;
-                        if (in_beam && ray_meets(ox, oy, oz, ux, uy, uz, o_l1, one)) append_id(id, rid, n_rays, cand, cnt, sp);
+                        if (in_beam && ray_meets(ox, oy, oz, ux, uy, uz, o_l1, one) &&
+                            ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, one, one_n))
+                            append_id(id, rid, n_rays, cand, cnt, sp);
                     }
                 }
             }
@@ -2315,7 +2340,7 @@ inline uint64_t spread21(uint64_t v) { // 21 bits -> every third bit
     v = (v | v << 2) & 0x1249249249249249ull;
     return v;
 }
-struct BoundSphere { double c[3]; double r; uint32_t id; };
+struct BoundSphere { double c[3]; double r; uint32_t id; double nrm[3]; bool tri; };
 // smallest-effort enclosing sphere of a run of spheres: centre = mean of their centres
 inline BoundSphere enclose(const BoundSphere *b, size_t count) {
     BoundSphere o{};
@@ -2349,6 +2374,8 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
                 b.r = std::max(b.r, sqrt(dx * dx + dy * dy + dz * dz) * (1 + 1e-12));
             }
             b.id = (uint32_t)p | CAND_TRI;
+            b.tri = true;
+            for (int a = 0; a < 3; a++) b.nrm[a] = t.normal[a];
         } else if (o.type == RT_OBJ_SPHERE) {
             for (int a = 0; a < 3; a++) b.c[a] = o.p[a];
             b.r = fabs(o.radius);
@@ -2406,9 +2433,16 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     const float nanf_ = nanf("");
     std::vector<float4> prim_rows(n_supers * 4096, make_float4(nanf_, nanf_, nanf_, nanf_)), chunk_rows(n_supers * 64, make_float4(nanf_, nanf_, nanf_, nanf_)), super_rows(n_supers);
     std::vector<uint32_t> prim_ids(n_supers * 4096, 0u);
+    std::vector<float4> prim_nrm(n_supers * 4096, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<BoundSphere> chunks(n_chunks);
     std::vector<float4> mini_rows(n_supers * 512, make_float4(nanf_, nanf_, nanf_, nanf_));
-    for (size_t i = 0; i < sorted.size(); i++) { prim_rows[i] = to_row(sorted[i]); prim_ids[i] = sorted[i].id; }
+    for (size_t i = 0; i < sorted.size(); i++) {
+        prim_rows[i] = to_row(sorted[i]);
+        prim_ids[i] = sorted[i].id;
+        const double *nn = sorted[i].nrm;
+        const bool unit = sorted[i].tri && fabs(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2] - 1.0) < 1e-9; // a degenerate triangle has none
+        if (unit) prim_nrm[i] = make_float4((float)nn[0], (float)nn[1], (float)nn[2], 1.f);
+    }
     for (size_t m = 0; m * 8 < sorted.size(); m++) mini_rows[m] = to_row(enclose(&sorted[m * 8], std::min<size_t>(8, sorted.size() - m * 8)));
     for (size_t j = 0; j < n_chunks; j++) {
         chunks[j] = enclose(&sorted[j * 64], std::min<size_t>(64, sorted.size() - j * 64));
@@ -2417,7 +2451,8 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     for (size_t k = 0; k < n_supers; k++) super_rows[k] = to_row(enclose(&chunks[k * 64], std::min<size_t>(64, n_chunks - k * 64)));
     GeneralTable &g = sc->general;
     int rc;
-    if ((rc = upload(sc, prim_rows, &g.prim)) || (rc = upload(sc, prim_ids, &g.prim_id)) || (rc = upload(sc, chunk_rows, &g.chunk)) ||
+    if ((rc = upload(sc, prim_rows, &g.prim)) || (rc = upload(sc, prim_ids, &g.prim_id)) || (rc = upload(sc, prim_nrm, &g.prim_n)) ||
+        (rc = upload(sc, chunk_rows, &g.chunk)) ||
         (rc = upload(sc, mini_rows, &g.mini)) ||
         (rc = upload(sc, super_rows, &g.super)) || (rc = upload(sc, planes, &g.plane_id)))
         return rc;
