@@ -62,14 +62,20 @@
 #define CAND_CAP 32         // candidate slots per ray; overflowing rays fall back to brute force
 // a candidate is the primitive index plus the kind of exact test it needs (the search copies the
 // kind bits from .w of the primitive's first L2 row)
-// A ray with more than CAND_CAP candidates (a ray skimming a finely tessellated surface) spills the rest as
-// (rid, id) pairs into one list per bundle; the exact tests of such a ray scan that list.  Only if the list
-// itself is full does the ray fall back to the ordered fp64 walk over every primitive.
-#define POOL_CAP (1u << 20)
-struct Spill { uint2 *pool; uint32_t *count; };
-__device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, uint32_t id) {
+// A ray with more than CAND_CAP candidates (a ray skimming a finely tessellated surface) spills the rest into
+// one pool per bundle as a chain of its own: an entry is (id, index of the ray's previous entry), the ray's
+// newest entry is in head[rid], and the exact tests of such a ray follow its chain.  `cnt` is the ray's
+// candidate count before this one: at CAND_CAP the chain starts.  Only if the pool itself is full does the ray
+// fall back to the ordered fp64 walk over every primitive.
+#define POOL_CAP (1u << 22)
+#define POOL_END 0xffffffffu
+struct Spill { uint2 *pool; uint32_t *count; uint32_t *head; };
+__device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, uint32_t id, uint32_t cnt) {
     const uint32_t at = atomicAdd(sp.count, 1u);
-    if (at < POOL_CAP) sp.pool[at] = make_uint2(rid, id);
+    if (at < POOL_CAP) {
+        sp.pool[at] = make_uint2(id, cnt == CAND_CAP ? POOL_END : sp.head[rid]);
+        sp.head[rid] = at;
+    }
 }
 #define CAND_SPHERE 0x40000000u
 #define CAND_TRI 0x80000000u
@@ -839,7 +845,7 @@ __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, co
     }
     if (fminf(ea, fminf(eb, ec)) >= floor_) {
         if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = __float_as_uint(a.w); // row 0 carries the candidate id
-        else spill_candidate(sp, rid, __float_as_uint(a.w));
+        else spill_candidate(sp, rid, __float_as_uint(a.w), cnt);
         cnt++;
     }
 }
@@ -847,7 +853,7 @@ __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, co
 __device__ __forceinline__ void append_id(uint32_t id, uint32_t rid, uint32_t n_rays, uint32_t *cand, uint32_t &cnt,
                                           const Spill &sp) {
     if (cnt < CAND_CAP) cand[(size_t)cnt * n_rays + rid] = id;
-    else spill_candidate(sp, rid, id);
+    else spill_candidate(sp, rid, id, cnt);
     cnt++;
 }
 template <int KIND>
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
-    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g;
+    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g; sp.head = sp_all.head + g * n_rays;
     __shared__ float4 lds[2][PRIM_TILE];
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
-    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g;
+    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g; sp.head = sp_all.head + g * n_rays;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t total = active_rid ? *n_active : n_rays;
     if (blockIdx.x * (PACKET_THREADS * PR) >= total) return;
@@ -1428,10 +1434,12 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
                 for (int j = 0; j < CAND_BATCH; j++)
                     if (k0 + j < n_own) consider(id[j], rec[j]);
             }
-            for (uint32_t i = 0; i < n_spill; i++) { // only rays with more than CAND_CAP candidates
-                const uint2 entry = sp.pool[i];
-                if (entry.x == rid) consider(entry.y, s.prim_rec[entry.y & CAND_INDEX]);
-            }
+            if (n > CAND_CAP) // the ray's own chain in the pool
+                for (uint32_t i = sp.head[rid]; i != POOL_END;) {
+                    const uint2 entry = sp.pool[i];
+                    consider(entry.x, s.prim_rec[entry.x & CAND_INDEX]);
+                    i = entry.y;
+                }
             c.t_best = bt; c.prim_best = bprim;
             if (pass == 0 && zero_obj >= 0 && bobj == zero_obj && !two_zero) exclude = zero_obj; // once more without it
             else break;
@@ -1665,7 +1673,7 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (!(x < f.grid_w && y < f.grid_h)) break;
     Ray e = grid_ray(cam, f, x, y);
-    Spill none; none.pool = nullptr; none.count = nullptr;
+    Spill none; none.pool = nullptr; none.count = nullptr; none.head = nullptr;
     constexpr int LEVELS = REFLECT ? 4 : 1;
     uint32_t level_clr[LEVELS];
     double level_ks[LEVELS];
@@ -1745,7 +1753,7 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (!(x < f.grid_w && y < f.grid_h)) break;
     const Ray e = grid_ray(cam, f, x, y);
-    Spill none; none.pool = nullptr; none.count = nullptr;
+    Spill none; none.pool = nullptr; none.count = nullptr; none.head = nullptr;
     Closest c;
     closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
     uint32_t clr = 0u; // main.cpp:167,204: no hit -> Color(0,0,0)
@@ -2151,7 +2159,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
     for (int g = 0; g < cur.count; g++) {
         sum = shade_light(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
-            Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_CAP; sp.count = w.spill.count + g;
+            Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_CAP; sp.count = w.spill.count + g; sp.head = w.spill.head + (size_t)g * n;
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
@@ -2605,7 +2613,7 @@ static void free_tables(rt355_scene *sc) {
 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
-    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
+    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count, w.spill.head,
                   w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
@@ -2694,6 +2702,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.spill.pool, g * POOL_CAP * sizeof(uint2)));
     HIP_TRY(hipMalloc((void **)&w.spill.count, LIGHT_GROUP * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.spill.head, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, g * CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, g * (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX) * sizeof(uint32_t)));
