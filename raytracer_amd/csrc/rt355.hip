@@ -2287,7 +2287,8 @@ struct rt355_scene {
     bool has_general = false;
     double ks_abs_max = 0;                      // largest |ks| of the scene
     // timing / stats of the outstanding render
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_done = nullptr; // ev_done: the counters have reached host_counters
+    unsigned long long *host_counters = nullptr; // pinned copy of Work::counters, filled by the frame's last command
     std::vector<hipEvent_t> ev_search; // begin/end pairs
     std::vector<hipEvent_t> ev_resolve; // begin/end pairs
     int resolve_launches = 0;
@@ -2592,6 +2593,8 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     }
     HIP_TRY(hipEventCreate(&sc->ev_begin));
     HIP_TRY(hipEventCreate(&sc->ev_end));
+    HIP_TRY(hipEventCreate(&sc->ev_done));
+    HIP_TRY(hipHostMalloc((void **)&sc->host_counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
     void *ctr = nullptr;
     HIP_TRY(hipMalloc(&ctr, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     sc->owned.push_back(ctr);
@@ -2635,6 +2638,8 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (sc->d_dirs) (void)hipFree(sc->d_dirs);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
+    if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
+    if (sc->host_counters) (void)hipHostFree(sc->host_counters);
     for (hipEvent_t e : sc->ev_search) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->ev_resolve) (void)hipEventDestroy(e);
     delete sc;
@@ -3100,6 +3105,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, st));
+    HIP_TRY(hipMemcpyAsync(sc->host_counters, sc->work.counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(sc->ev_done, st));
     sc->pending = true;
     sc->pending_stats = stats;
     sc->pending_stream = st;
@@ -3114,10 +3122,10 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     if (!sc) return fail(RT355_ERR_ARG, "rt355_scene_sync: null scene");
     if (!sc->pending) return RT355_OK;
     HIP_TRY(hipSetDevice(sc->device));
-    HIP_TRY(hipEventSynchronize(sc->ev_end));
+    HIP_TRY(hipEventSynchronize(sc->ev_done));
     sc->pending = false;
-    unsigned long long shards[COUNTER_SHARDS * COUNTER_STRIDE], ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(shards, sc->work.counters, sizeof shards, hipMemcpyDeviceToHost));
+    const unsigned long long *shards = sc->host_counters;
+    unsigned long long ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < COUNTER_SHARDS; i++)
         for (int j = 0; j < 8; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
     float ms = 0;
