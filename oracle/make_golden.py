@@ -143,7 +143,7 @@ def main():
         tex[f"{tag}_ang"] = ang
         tex[f"{tag}_sphere"] = R.texture_many(t, 1, ang)
     np.savez_compressed(os.path.join(OUT, "texture_lookups.npz"), **tex)
-    # 5. values the survey recorded from a run of the reference main.cpp path
+    # 5. pixel values recorded from a run of the reference main.cpp path itself
     meta["baseline_md_samples"] = {
         "800x600_1light": {"(0,0)": [181] * 3, "(400,300)": [11] * 3, "(200,300)": [65, 130, 65],
                            "(600,200)": [180] * 3, "(400,75)": [181] * 3, "(799,599)": [170] * 3},

@@ -12,7 +12,7 @@
 // on the path (Scene::SetCamera 255-262, CalcView 269-276, the closest-hit loop of
 // CalcSubPixel 42-91, the alias==0 branch of CalcPixel 326-332 and setPixels 355-370)
 // are therefore re-expressed below with the reference's own vector/colour types.  That
-// part is pinned by the 18 pixel values BASELINE.md records from a run of main.cpp itself.
+// part is pinned by 18 pixel values recorded from a run of main.cpp itself (tests/golden/meta.json, baseline_md_samples).
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
