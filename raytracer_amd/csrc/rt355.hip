@@ -69,12 +69,16 @@
 // fall back to the ordered fp64 walk over every primitive.
 #define POOL_CAP (1u << 22)
 #define POOL_END 0xffffffffu
-struct Spill { uint2 *pool; uint32_t *count; uint32_t *head; };
+// A bundle's pool is POOL_CAP entries followed by head[n_rays] (so that a pool is one pointer in the kernels).
+#define POOL_STRIDE(n_rays) ((size_t)POOL_CAP + ((size_t)(n_rays) + 1) / 2) /* in entries of 8 bytes */
+struct Spill { uint2 *pool; uint32_t *count; };
+__device__ __forceinline__ uint32_t *spill_head(const Spill &sp) { return (uint32_t *)(sp.pool + POOL_CAP); }
 __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, uint32_t id, uint32_t cnt) {
     const uint32_t at = atomicAdd(sp.count, 1u);
     if (at < POOL_CAP) {
-        sp.pool[at] = make_uint2(id, cnt == CAND_CAP ? POOL_END : sp.head[rid]);
-        sp.head[rid] = at;
+        uint32_t *head = spill_head(sp);
+        sp.pool[at] = make_uint2(id, cnt == CAND_CAP ? POOL_END : head[rid]);
+        head[rid] = at;
     }
 }
 #define CAND_SPHERE 0x40000000u
@@ -881,7 +885,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search(Tables t_all, int n_p
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
-    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g; sp.head = sp_all.head + g * n_rays;
+    Spill sp; sp.pool = sp_all.pool + g * POOL_STRIDE(n_rays); sp.count = sp_all.count + g;
     __shared__ float4 lds[2][PRIM_TILE];
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * RAYS_PER_TILE + t;
@@ -1010,7 +1014,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
-    Spill sp; sp.pool = sp_all.pool + g * POOL_CAP; sp.count = sp_all.count + g; sp.head = sp_all.head + g * n_rays;
+    Spill sp; sp.pool = sp_all.pool + g * POOL_STRIDE(n_rays); sp.count = sp_all.count + g;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t total = active_rid ? *n_active : n_rays;
     if (blockIdx.x * (PACKET_THREADS * PR) >= total) return;
@@ -1435,7 +1439,7 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
                     if (k0 + j < n_own) consider(id[j], rec[j]);
             }
             if (n > CAND_CAP) // the ray's own chain in the pool
-                for (uint32_t i = sp.head[rid]; i != POOL_END;) {
+                for (uint32_t i = spill_head(sp)[rid]; i != POOL_END;) {
                     const uint2 entry = sp.pool[i];
                     consider(entry.x, s.prim_rec[entry.x & CAND_INDEX]);
                     i = entry.y;
@@ -1645,7 +1649,9 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
     if (!h.no_border) clr = calc_border(sh, clr, h.border_w);
     double shd = 0.5; // shader.h:396-398
     if (!(dot(h.nh, vmul(nhl, -1)) <= 0)) {
-        const Ray sr = mkview(h.ph, vmul(nhl, -1)); // shader.h:395,404
+        Ray sr; // View(ph, nhl * (-1)), shader.h:395,404
+        if (L.type == 0) { sr.pe = h.ph; sr.npe = ld3(L.shadow_dir); }
+        else sr = mkview(h.ph, vmul(nhl, -1));
         const double t_min = occluder(sr);
         const double Ld = vlen(vsub(ld3(L.position), h.ph)); // shader.h:412
         shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
@@ -1673,7 +1679,7 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (!(x < f.grid_w && y < f.grid_h)) break;
     Ray e = grid_ray(cam, f, x, y);
-    Spill none; none.pool = nullptr; none.count = nullptr; none.head = nullptr;
+    Spill none; none.pool = nullptr; none.count = nullptr;
     constexpr int LEVELS = REFLECT ? 4 : 1;
     uint32_t level_clr[LEVELS];
     double level_ks[LEVELS];
@@ -1753,7 +1759,7 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
     rid_to_xy(rid, f.tiles_x, &x, &y);
     if (!(x < f.grid_w && y < f.grid_h)) break;
     const Ray e = grid_ray(cam, f, x, y);
-    Spill none; none.pool = nullptr; none.count = nullptr; none.head = nullptr;
+    Spill none; none.pool = nullptr; none.count = nullptr;
     Closest c;
     closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
     uint32_t clr = 0u; // main.cpp:167,204: no hit -> Color(0,0,0)
@@ -2159,7 +2165,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
     for (int g = 0; g < cur.count; g++) {
         sum = shade_light(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
-            Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_CAP; sp.count = w.spill.count + g; sp.head = w.spill.head + (size_t)g * n;
+            Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_STRIDE(n); sp.count = w.spill.count + g;
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
@@ -2616,7 +2622,7 @@ static void free_tables(rt355_scene *sc) {
 
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
-    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count, w.spill.head,
+    void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
                   w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d};
     for (void *p : ps) if (p) (void)hipFree(p);
     unsigned long long *keep = w.counters;
@@ -2705,9 +2711,8 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.rec_sum, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.ray32, g * n * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, g * n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.spill.pool, g * POOL_CAP * sizeof(uint2)));
+    HIP_TRY(hipMalloc((void **)&w.spill.pool, g * POOL_STRIDE(n) * sizeof(uint2)));
     HIP_TRY(hipMalloc((void **)&w.spill.count, LIGHT_GROUP * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&w.spill.head, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, g * CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, g * (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX) * sizeof(uint32_t)));
@@ -2799,6 +2804,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         memcpy(hl[i].direction, l.direction, sizeof hl[i].direction);
         memcpy(hl[i].color, l.color, sizeof hl[i].color);
         hl[i].type = l.type; hl[i].pad_ = 0;
+        put3(hl[i].shadow_dir, hnormalize(hmul(H3(l.direction), -1.0)));
     }
     if (nl > sc->lights_cap) {
         if (sc->d_lights) (void)hipFree(sc->d_lights);

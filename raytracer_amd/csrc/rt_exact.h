@@ -88,6 +88,9 @@ struct DTexture {
 struct DLight {
     double position[3], direction[3], color[3];
     int32_t type, pad_;
+    // directional light: the shadow rays' direction Normalize(-direction) (shader.h:395, view.h:23), the same for
+    // every hit, evaluated once on the host (IEEE sqrt and division, the operations the device would repeat)
+    double shadow_dir[3];
 };
 struct DCamera { // Scene::SetCamera's results (main.cpp:255-262), computed on the host in double
     double p_eye[3], p00[3], n0[3], n1[3];
