@@ -112,6 +112,14 @@ inline rt355_shader rt355_shader_of(const Shader &shd, const std::vector<rt355_l
     return s;
 }
 
+// The direction set of the gather shaders: the global `geo` that main.cpp:557 fills with Geodesic().
+inline int rt355_set_directions(rt355_scene *scene, const std::vector<Vector3D> &geo) {
+    std::vector<double> xyz;
+    xyz.reserve(geo.size() * 3);
+    for (const Vector3D &g : geo) { xyz.push_back(g.x); xyz.push_back(g.y); xyz.push_back(g.z); }
+    return rt355_scene_set_directions(scene, xyz.data(), (int32_t)geo.size());
+}
+
 // SceneT = the reference's Scene (main.cpp:215-265): only its public camera fields are read.
 template <class SceneT>
 inline rt355_camera rt355_camera_of(const SceneT &sce) {
