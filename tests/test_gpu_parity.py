@@ -317,6 +317,13 @@ def test_error_behaviour(api):
         r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, alias=-1)
     with pytest.raises(api.Rt355Error, match="ARG"):
         r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, row_begin=40, row_end=20)
+    with pytest.raises(api.Rt355Error, match="shading"):
+        r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, shading=7)
+    L = api.lib()
+    assert L.rt355_scene_set_directions(r.handle, None, 5) == -1 and b"bad argument" in L.rt355_last_error()
+    assert L.rt355_scene_set_directions(r.handle, None, -1) == -1
+    assert L.rt355_scene_set_directions(None, None, 0) == -1
+    r.set_directions(np.zeros((0, 3)))  # clearing the set is allowed
     r.close()
 
 
