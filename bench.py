@@ -292,7 +292,7 @@ def measure(name, args, ctx, headline):
                       "packet_survivors": stats["packet_survivors"]}}
     # ---- kernel-time breakdown: a few more frames, HIP-event times read back after each
     K = 3
-    acc, stats = run_frames(r, cam, shader, o, fb, stream, K, gather, detail=True)
+    acc, stats = run_frames(r, cam, shader, o, fb, stream, K, None, detail=True)  # rank 0 alone: no gather here
     searched = acc["search_launches"] > 0
     nl = len(shader.lights)
     out["kernel_time"] = {"search_ms_per_frame": round(acc["search_ms"] / K, 4),

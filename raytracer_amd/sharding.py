@@ -40,7 +40,10 @@ def gather_frame(local_frame, rank: int, world: int, dst: int = 0):
         return local_frame
     pad = max(e - b for b, e in rows)
     b, e = rows[rank]
-    send = torch.zeros((pad,) + tuple(local_frame.shape[1:]), dtype=local_frame.dtype, device=local_frame.device)
+    # gloo moves host memory: with that backend a slab on the GPU is staged through the host (RCCL takes it as it is)
+    via_host = local_frame.is_cuda and dist.get_backend() == "gloo"
+    send = torch.zeros((pad,) + tuple(local_frame.shape[1:]), dtype=local_frame.dtype,
+                       device="cpu" if via_host else local_frame.device)
     send[: e - b].copy_(local_frame[b:e])
     bufs = [torch.zeros_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, bufs, dst=dst)
