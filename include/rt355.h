@@ -37,11 +37,13 @@ extern "C" {
 #define RT355_OBJ_PLANE  0
 #define RT355_OBJ_SPHERE 1
 #define RT355_OBJ_MESH   2
+#define RT355_OBJ_ENVIRONMENT 3 /* "Environment" anyobject.h:223: a sphere seen from inside whose (textured) colour
+                                   Shader::shading returns unlit (shader.h:70-72); fields as for a Sphere */
 
 /* One entry of Scene::objs (main.cpp:229).  Order is significant: the closest-hit loop
  * keeps the first object on equal t (main.cpp:68). */
 typedef struct rt355_object {
-    double p[3];      /* Plane::pi (anyobject.h:43) | Sphere::pCenter (:101)                 */
+    double p[3];      /* Plane::pi (anyobject.h:43) | Sphere / Environment::pCenter (:101)   */
     double n[3];      /* Plane::ni (:46), used as given (not normalised, :86)               */
     double n0[3];     /* Plane::n0 (:44) | Sphere::n0 (:103); texture axes                  */
     double n1[3];     /* Sphere::n1 (:104).  For a plane the library derives

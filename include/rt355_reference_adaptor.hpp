@@ -2,7 +2,7 @@
 //
 // Include AFTER the reference's own headers (vector3D.h, color.h, texture.h, shader.h,
 // anyobject.h): it walks a `vector<AnyObject*>` (Scene::objs, main.cpp:229), down-casts by
-// GetObjectType() ("Plane" anyobject.h:89, "Sphere" :161, "Mesh" :672) and fills the plain-C
+// GetObjectType() ("Plane" anyobject.h:89, "Sphere" :161, "Environment" :223, "Mesh" :672) and fills the plain-C
 // descriptors of rt355.h.  It holds no reference code, only member reads.
 //
 // Two members of the reference are private and cannot be read from outside:
@@ -55,9 +55,9 @@ inline Rt355Flattened rt355_flatten(const std::vector<AnyObject *> &objs,
             Plane *p = (Plane *)a;
             o.type = RT355_OBJ_PLANE;
             put(o.p, p->pi); put(o.n, p->ni); put(o.n0, p->n0); put(o.n1, p->n1); put(o.rgb, p->clr);
-        } else if (kind == "Sphere") {
+        } else if (kind == "Sphere" || kind == "Environment") { // Environment derives from Sphere (anyobject.h:171)
             Sphere *s = (Sphere *)a;
-            o.type = RT355_OBJ_SPHERE;
+            o.type = kind == "Sphere" ? RT355_OBJ_SPHERE : RT355_OBJ_ENVIRONMENT;
             put(o.p, s->pCenter); o.radius = s->radius;
             put(o.n0, s->n0); put(o.n1, s->n1); put(o.n2, s->n2); put(o.rgb, s->clr);
         } else if (kind == "Mesh") {

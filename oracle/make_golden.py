@@ -40,7 +40,8 @@ def main():
     # 1b. supersampled frames (alias > 0): CalcPixel's sub-sample loop run with the reference's classes, the
     #     jitter taken from rt355_jitter in place of rand()
     meta["alias_cases"] = []
-    for name, alias in (("default_2lights", 2), ("textured", 3), ("mesh", 2), ("spheres300_dir", 3)):
+    for name, alias in (("default_2lights", 2), ("textured", 3), ("mesh", 2), ("spheres300_dir", 3),
+                        ("environment", 2)):
         sc, sh, cam, w, h = S.small_case(name)
         w, h = w // 2, h // 2
         cam = S.default_camera(w, h)
@@ -56,7 +57,9 @@ def main():
     for name, level, shading, alias in (("default_2lights", 0, B.SHADING_BLEED, 0), ("default_2lights", 2, B.SHADING_BLEED, 0),
                                         ("default_2lights", 1, B.SHADING_OCCLUSION, 0), ("mesh", 1, B.SHADING_BLEED, 2),
                                         ("inside", 1, B.SHADING_OCCLUSION, 2), ("textured", 1, B.SHADING_BLEED, 0),
-                                        ("mirrors_mesh", 0, B.SHADING_BLEED, 0)):
+                                        ("mirrors_mesh", 0, B.SHADING_BLEED, 0), ("environment", 1, B.SHADING_BLEED, 0),
+                                        ("environment_spheres", 0, B.SHADING_OCCLUSION, 0),
+                                        ("environment_spheres", 0, B.SHADING_BLEED, 2)):
         sc, sh, cam, w, h = S.small_case(name)
         w, h = w // 2, h // 2
         cam = S.default_camera(w, h)

@@ -134,6 +134,10 @@ bool build(const rt355_scene_desc *d, const char *tmpdir, RefScene &rs) {
             obj = new Plane(pnt(o.p), vec(o.n), vec(o.n0), clr, o.ks);
         } else if (o.type == RT355_OBJ_SPHERE) {
             obj = new Sphere(pnt(o.p), o.radius, clr, vec(o.n0), vec(o.n1), vec(o.n2), o.ks);
+        } else if (o.type == RT355_OBJ_ENVIRONMENT) {
+            Environment *env = new Environment(pnt(o.p), o.radius, clr, vec(o.n0), vec(o.n1), vec(o.n2), o.ks);
+            env->n0 = vec(o.n0); env->n1 = vec(o.n1); env->n2 = vec(o.n2); // the descriptor holds the members as stored
+            obj = env;
         } else {
             std::cout.rdbuf(sink.rdbuf());
             Mesh *m = new Mesh("/nonexistent/rt355.obj", Point3D(0, 0, 0), 1, o.ks);
@@ -451,7 +455,7 @@ int ref_adaptor_roundtrip(const rt355_scene_desc *d, const rt355_shader *sh, con
         if (a.type != b.type || a.texture_type != b.texture_type || memcmp(a.rgb, b.rgb, 3)) return 10 + i;
         if (a.ks != b.ks || a.fresnel != b.fresnel || a.ior != b.ior) return 10 + i;
         if (a.type == RT355_OBJ_PLANE && (memcmp(a.p, b.p, 24) || memcmp(a.n, b.n, 24) || memcmp(a.n0, b.n0, 24))) return 10 + i;
-        if (a.type == RT355_OBJ_SPHERE && (memcmp(a.p, b.p, 24) || a.radius != b.radius || memcmp(a.n0, b.n0, 72))) return 10 + i;
+        if ((a.type == RT355_OBJ_SPHERE || a.type == RT355_OBJ_ENVIRONMENT) && (memcmp(a.p, b.p, 24) || a.radius != b.radius || memcmp(a.n0, b.n0, 72))) return 10 + i;
         if (a.type == RT355_OBJ_MESH && (a.tri_begin != b.tri_begin || a.tri_count != b.tri_count)) return 10 + i;
         if ((a.tex0 >= 0) != (b.tex0 >= 0) || (a.tex1 >= 0) != (b.tex1 >= 0)) return 10 + i;
         if (a.tex0 >= 0) {

@@ -135,6 +135,26 @@ static hit sphere_isect(const rt355_object *o, ray e) {
     return h;
 }
 
+/* Environment::CalcIntersect, anyobject.h:199-220.  Every call on the path goes through an AnyObject* (so the
+ * default argument is the base class's 0, anyobject.h:23) or passes 0 itself (shader.h:128,174): `inside` is 0 with
+ * the origin inside the sphere, -1 outside; t is the far root. */
+static hit environment_isect(const rt355_object *o, ray e) {
+    hit h; memset(&h, 0, sizeof h);
+    v3 c = from3(o->p);
+    double r = o->radius;
+    v3 ec = vsub(e.pe, c);
+    int inside = 0;
+    if (dot(ec, ec) - r * r >= 0.00001) inside = -1;
+    double B = dot(e.npe, vsub(c, e.pe));
+    double Cc = dot(ec, ec) - r * r;
+    double delta = B * B - Cc;
+    if (delta < 0) { h.t = -1; return h; }
+    h.t = B + sqrt(delta);
+    h.ph = vadd(e.pe, vmul(e.npe, h.t));
+    h.nh = vmul(normalize(vsub(c, h.ph)), inside);
+    return h;
+}
+
 /* Triangle::CalcIntersect, anyobject.h:475-522; u,v returned for GetUV (:524-526) */
 static hit tri_isect(const otri *t, ray e, double *u_out, double *v_out) {
     hit h; memset(&h, 0, sizeof h);
@@ -184,6 +204,7 @@ static hit obj_isect(const oscene *s, int i, ray e) {
     const rt355_object *o = &s->d->objects[i];
     if (o->type == RT355_OBJ_PLANE) return plane_isect(o, e);
     if (o->type == RT355_OBJ_SPHERE) return sphere_isect(o, e);
+    if (o->type == RT355_OBJ_ENVIRONMENT) return environment_isect(o, e);
     return mesh_isect(s, o, e);
 }
 
@@ -220,7 +241,7 @@ static col tex_plane(const rt355_texture *t, double x, double y) {        /* tex
 static void texture_mapping(const oscene *s, const rt355_object *o, v3 ph, double uvx, double uvy,
                             col *cm0, col *cm1) {
     const rt355_texture *t0 = &s->d->textures[o->tex0], *t1 = &s->d->textures[o->tex1];
-    if (o->type == RT355_OBJ_SPHERE) {
+    if (o->type == RT355_OBJ_SPHERE || o->type == RT355_OBJ_ENVIRONMENT) { /* shader.h:198 */
         v3 c = from3(o->p);
         double x = dot(from3(o->n0), vsub(ph, c)) / o->radius;
         double y = dot(from3(o->n1), vsub(ph, c)) / o->radius;
@@ -317,6 +338,7 @@ static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_bor
     const rt355_shader *sh = cx->sh;
     col clr_sum = C(0, 0, 0);
     if (o->texture_type == 1) texture_mapping(cx->s, o, ph, uvx, uvy, &cm0, &cm1);
+    if (o->type == RT355_OBJ_ENVIRONMENT) return cm0; /* shader.h:70-72 */
     for (int k = 0; k < sh->n_lights; k++) {
         const rt355_light *L = &sh->lights[k];
         v3 nhl;
@@ -345,7 +367,7 @@ static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double ref
         hit h = obj_isect(cx->s, i, eye);
         if (h.t >= 0 && h.t < t_min) {
             t_min = h.t; idx = i; best = h;
-            no_border = (cx->s->d->objects[i].type != RT355_OBJ_SPHERE);
+            no_border = (cx->s->d->objects[i].type == RT355_OBJ_PLANE || cx->s->d->objects[i].type == RT355_OBJ_MESH);
         }
     }
     if (t_min != FLT_MAX) {

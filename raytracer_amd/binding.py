@@ -14,7 +14,7 @@ from typing import List, Sequence
 
 import numpy as np
 
-OBJ_PLANE, OBJ_SPHERE, OBJ_MESH = 0, 1, 2
+OBJ_PLANE, OBJ_SPHERE, OBJ_MESH, OBJ_ENVIRONMENT = 0, 1, 2, 3
 MODE_ALLPAIRS, MODE_BRUTE, MODE_PACKET = 0, 1, 2
 SHADING_LIGHTS, SHADING_OCCLUSION, SHADING_BLEED = 0, 1, 2
 
@@ -141,6 +141,15 @@ class Scene:
         o = self._new(OBJ_SPHERE, clr, ks)
         o["p"] = center; o["radius"] = radius
         o["n0"] = n0; o["n1"] = n1; o["n2"] = n2
+        self.objects.append(o)
+        return len(self.objects) - 1
+
+    def add_environment(self, center, radius, clr, n0=(1, 0, 0), n1=(0, 1, 0), n2=(0, 0, 1), ks=0.0):
+        """Environment(Point3D, double radius, Color, Vector3D n0, n1, n2, double ks) anyobject.h:181: the sky
+        sphere seen from inside; its constructor normalises the three axes."""
+        o = self._new(OBJ_ENVIRONMENT, clr, ks)
+        o["p"] = center; o["radius"] = radius
+        o["n0"] = _normalize(n0); o["n1"] = _normalize(n1); o["n2"] = _normalize(n2)
         self.objects.append(o)
         return len(self.objects) - 1
 

@@ -83,6 +83,7 @@ __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, u
 }
 #define CAND_SPHERE 0x40000000u
 #define CAND_TRI 0x80000000u
+#define CAND_ENVIRONMENT (CAND_SPHERE | CAND_TRI) // both bits: an Environment (its record is a sphere's)
 #define CAND_INDEX 0x3fffffffu
 #define CAND_UNSEARCHED 0xffffffffu // candidate count of a ray the search left to the fp64 walk over everything
 #ifndef CAND_BATCH
@@ -188,7 +189,8 @@ __device__ __forceinline__ float4 nan4() {
 __device__ __forceinline__ uint32_t cand_id(const SceneView &s, int prim) {
     if (prim < 0) return 0u;
     if (s.prim_tri[prim] >= 0) return (uint32_t)prim | CAND_TRI;
-    return (uint32_t)prim | ((s.objects[s.prim_obj[prim]].type == RT_OBJ_SPHERE) ? CAND_SPHERE : 0u);
+    const int type = s.objects[s.prim_obj[prim]].type;
+    return (uint32_t)prim | (type == RT_OBJ_SPHERE ? CAND_SPHERE : (type == RT_OBJ_ENVIRONMENT ? CAND_ENVIRONMENT : 0u));
 }
 // L1[i] = (ox, oy, oz, -thr): unit axis and negated cosine threshold of a cone, seen from the
 // bundle origin, that contains primitive i.  A ray with unit direction d can only hit i if
@@ -209,7 +211,7 @@ __device__ __forceinline__ TableRow bundle_origin_row(const SceneView &s, d3 O, 
         d3 ctr; double rad; bool sphere_like = false;
         if (tri < 0) {
             const DObject &o = s.objects[obj];
-            if (o.type == RT_OBJ_PLANE) { l1 = always; sin_t = 0.f; }
+            if (o.type == RT_OBJ_PLANE || o.type == RT_OBJ_ENVIRONMENT) { l1 = always; sin_t = 0.f; } // (an Environment surrounds the scene)
             else { ctr = ld3(o.p); rad = fabs(o.radius); sphere_like = true; }
         } else {
             const DTriangle &t = s.tris[tri];
@@ -301,7 +303,9 @@ __device__ __forceinline__ TableRow bundle_direction_row(const SceneView &s, con
         d3 ctr; double rad = 0; bool round_like = false;
         if (tri < 0) {
             const DObject &o = s.objects[obj];
-            if (o.type == RT_OBJ_PLANE) {
+            if (o.type == RT_OBJ_ENVIRONMENT) {
+                l1 = always;
+            } else if (o.type == RT_OBJ_PLANE) {
                 // Plane::CalcIntersect misses when ni . npe >= 0 (anyobject.h:80); npe = w up to rounding
                 d3 ni = ld3(o.n);
                 l1 = (dot(ni, w) > 1e-12 * vlen(ni)) ? never : always;
@@ -1408,7 +1412,10 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
             auto consider = [&](uint32_t id, const double4 &rec) {
                 const int prim = (int)(id & CAND_INDEX);
                 double t; int obj = -1;
-                if (id & CAND_SPHERE) {
+                if ((id & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
+                    int inside;
+                    t = environment_t_rec(rec, e, &inside);
+                } else if (id & CAND_SPHERE) {
                     t = sphere_t_rec(rec, e);
                 } else if (id & CAND_TRI) {
                     obj = __double2loint(rec.x);
@@ -1492,7 +1499,10 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
             for (int j = 0; j < CAND_BATCH; j++) {
                 if (k0 + j >= n) break;
                 double t;
-                if (id[j] & CAND_SPHERE) {
+                if ((id[j] & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
+                    int inside;
+                    t = environment_t_rec(rec[j], e, &inside);
+                } else if (id[j] & CAND_SPHERE) {
                     t = sphere_t_rec(rec[j], e);
                 } else if (id[j] & CAND_TRI) {
                     int outside; d3 ph; double u, v;
@@ -1608,6 +1618,11 @@ __device__ __forceinline__ HitGeo hit_geometry(const SceneView &s, const Ray &e,
         int outside = (dot(ni, vsub(e.pe, ld3(o.p))) <= 0) ? -1 : 1; // anyobject.h:71-77
         h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :85
         h.nh = vmul(ni, (double)outside);                            // :86
+    } else if (o.type == RT_OBJ_ENVIRONMENT) {
+        int inside;
+        environment_t_rec(make_double4(o.p[0], o.p[1], o.p[2], o.radius), e, &inside);
+        h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // anyobject.h:215
+        h.nh = vmul(normalize(vsub(ld3(o.p), h.ph)), (double)inside); // :218
     } else {
         int outside;
         sphere_t(o, e, &outside);
@@ -1624,6 +1639,7 @@ struct HitRec {
     uint32_t cm0, cm1;
     int obj;
     bool no_border;
+    bool emissive; // an Environment: Shader::shading returns its (textured) colour before the lights (shader.h:70-72)
 };
 __device__ __forceinline__ HitRec primary_record(const SceneView &s, const ShaderView &sh, const Ray &e, const Closest &c) {
     const HitGeo g = hit_geometry(s, e, c);
@@ -1632,7 +1648,8 @@ __device__ __forceinline__ HitRec primary_record(const SceneView &s, const Shade
     const DObject &o = s.objects[h.obj];
     h.cm0 = o.rgb; h.cm1 = sh.ambient;
     if (o.texture_type == 1) texture_mapping(s, o, h.ph, g.uvx, g.uvy, &h.cm0, &h.cm1); // shader.h:53-58
-    h.no_border = (o.type != RT_OBJ_SPHERE);                         // main.cpp:74
+    h.no_border = (o.type == RT_OBJ_PLANE || o.type == RT_OBJ_MESH); // main.cpp:74
+    h.emissive = (o.type == RT_OBJ_ENVIRONMENT);
     h.reh = mirror_dir(h.nh, e.npe);
     h.border_w = h.no_border ? 0.0 : border_weight(e.pe, h.ph, h.nh);
     return h;
@@ -1700,7 +1717,8 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
             if (level == 0) n_hit = 1;
             const HitRec h = primary_record(s, sh, e, c);
             ph = h.ph; nh = h.nh; obj = h.obj;
-            for (int k = 0; k < sh.n_lights; k++)
+            if (h.emissive) sum = h.cm0;
+            for (int k = 0; !h.emissive && k < sh.n_lights; k++)
                 sum = shade_light(sh, k, h, sum, [&](const Ray &sr) {
                     Closest o;
                     closest_hit(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
@@ -2038,22 +2056,23 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         break;
     }
     n_hit = f.level > 0 ? 0 : 1; // rt355_stats.primary_hits counts camera rays
-    if (sh.n_lights == 0 && f.level < 0) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
+    const bool environment = s.objects[s.prim_obj[c.prim_best]].type == RT_OBJ_ENVIRONMENT;
+    if (sh.n_lights == 0 && f.level < 0 && !environment) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
         w.rec_obj[rid] = s.prim_obj[c.prim_best];
         store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
-    if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u); // (levels: the mirror ray still needs ph and nh)
     const HitRec h = primary_record(s, sh, e, c);
+    if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, h.emissive ? h.cm0 : 0u); // (levels: the mirror ray still needs ph and nh)
     ph = h.ph; nh = h.nh;
-    got_hit = true;
+    got_hit = !h.emissive; // an Environment is not lit: no shadow rays (shader.h:70-72)
     const size_t n = f.n_rays;
     w.rec_obj[rid] = h.obj;
     w.rec_d[0 * n + rid] = ph.x; w.rec_d[1 * n + rid] = ph.y; w.rec_d[2 * n + rid] = ph.z;
     w.rec_d[3 * n + rid] = nh.x; w.rec_d[4 * n + rid] = nh.y; w.rec_d[5 * n + rid] = nh.z;
     w.rec_d[6 * n + rid] = h.reh.x; w.rec_d[7 * n + rid] = h.reh.y; w.rec_d[8 * n + rid] = h.reh.z;
     if (!h.no_border) w.rec_d[9 * n + rid] = h.border_w;
-    w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u);
+    w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u) | (h.emissive ? (1u << 25) : 0u);
     w.rec_cm1[rid] = h.cm1;
     } while (0);
     const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, got_hit && sh.n_lights, ph, nh);
@@ -2161,6 +2180,10 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     const uint32_t cm0w = w.rec_cm0[rid];
     h.cm0 = cm0w & 0xffffffu; h.cm1 = w.rec_cm1[rid];
     h.no_border = (cm0w >> 24) & 1u;
+    if ((cm0w >> 25) & 1u) { // an Environment: its colour as it is (shader.h:70-72)
+        if (last) store_pixel(pixmap, f, w, rid, x, y, h.cm0);
+        break;
+    }
     h.border_w = h.no_border ? 0.0 : w.rec_d[9 * n + rid];
     uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
     for (int g = 0; g < cur.count; g++) {
@@ -2215,6 +2238,10 @@ __global__ void k_probe_intersect(SceneView s, int obj, const double *__restrict
         int outside;
         t = sphere_t(o, e, &outside);
         if (t != -1) { ph = vadd(e.pe, vmul(e.npe, t)); nh = vmul(normalize(vsub(ph, ld3(o.p))), (double)outside); }
+    } else if (o.type == RT_OBJ_ENVIRONMENT) {
+        int inside;
+        t = environment_t_rec(make_double4(o.p[0], o.p[1], o.p[2], o.radius), e, &inside);
+        if (t != -1) { ph = vadd(e.pe, vmul(e.npe, t)); nh = vmul(normalize(vsub(ld3(o.p), ph)), (double)inside); }
     } else {
         double t_min = RT_FLT_MAX; int best = -1;
         for (int q = 0; q < o.tri_count; q++) {
@@ -2395,8 +2422,8 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
             for (int a = 0; a < 3; a++) b.c[a] = o.p[a];
             b.r = fabs(o.radius);
             b.id = (uint32_t)p | CAND_SPHERE;
-        } else {
-            planes.push_back((uint32_t)p);
+        } else { // planes, and environments (a sphere around everything would only bloat its group): candidates of every ray
+            planes.push_back((uint32_t)p | (o.type == RT_OBJ_ENVIRONMENT ? CAND_ENVIRONMENT : 0u));
             continue;
         }
         if (!(std::isfinite(b.c[0]) && std::isfinite(b.c[1]) && std::isfinite(b.c[2]) && std::isfinite(b.r)))
@@ -2493,14 +2520,14 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         return fail(RT355_ERR_ARG, "rt355_scene_create: inconsistent counts/pointers");
     std::vector<DObject> objs(d->n_objects);
     std::vector<DTriangle> tris(d->n_triangles);
-    std::vector<int32_t> prim_obj, prim_tri, by_kind[3];
+    std::vector<int32_t> prim_obj, prim_tri, by_kind[4]; // planes, spheres, triangles, environments
     std::vector<double4> prim_rec;
     bool any_ks = false;
     double rmax = 0, extent = 0, ks_abs_max = 0;
     for (int i = 0; i < d->n_objects; i++) {
         const rt355_object &o = d->objects[i];
-        if (o.type != RT355_OBJ_PLANE && o.type != RT355_OBJ_SPHERE && o.type != RT355_OBJ_MESH)
-            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": only Plane, Sphere and Mesh are accelerated");
+        if (o.type != RT355_OBJ_PLANE && o.type != RT355_OBJ_SPHERE && o.type != RT355_OBJ_MESH && o.type != RT355_OBJ_ENVIRONMENT)
+            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": only Plane, Sphere, Environment and Mesh are accelerated");
         if (o.fresnel != 1)
             return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": fresnel != 1 (refraction, main.cpp:116-154, is not accelerated)");
         if (o.ks != 0) any_ks = true;
@@ -2532,9 +2559,9 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
                 prim_rec.push_back(index_rec(i, o.tri_begin + k));
             }
         } else {
-            by_kind[o.type == RT355_OBJ_SPHERE ? 1 : 0].push_back((int32_t)prim_obj.size());
+            by_kind[o.type == RT355_OBJ_SPHERE ? 1 : (o.type == RT355_OBJ_ENVIRONMENT ? 3 : 0)].push_back((int32_t)prim_obj.size());
             prim_obj.push_back(i); prim_tri.push_back(-1);
-            prim_rec.push_back(o.type == RT355_OBJ_SPHERE ? make_double4(o.p[0], o.p[1], o.p[2], o.radius) : index_rec(i, -1));
+            prim_rec.push_back(o.type == RT355_OBJ_PLANE ? index_rec(i, -1) : make_double4(o.p[0], o.p[1], o.p[2], o.radius));
         }
         if (prim_obj.size() > (size_t)CAND_INDEX)
             return fail(RT355_ERR_UNSUPPORTED, "more than 2^30 - 1 primitives");
@@ -2565,6 +2592,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     }
     std::vector<int32_t> kind_prims(by_kind[0]);
     kind_prims.insert(kind_prims.end(), by_kind[1].begin(), by_kind[1].end());
+    kind_prims.insert(kind_prims.end(), by_kind[3].begin(), by_kind[3].end());
     kind_prims.insert(kind_prims.end(), by_kind[2].begin(), by_kind[2].end());
     rt355_scene *sc = new rt355_scene();
     HIP_TRY(hipGetDevice(&sc->device));
@@ -2579,6 +2607,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->view.n_objects = d->n_objects;
     sc->view.n_prims = (int)prim_obj.size();
     sc->view.n_planes = (int)by_kind[0].size(); sc->view.n_spheres = (int)by_kind[1].size();
+    sc->view.n_envs = (int)by_kind[3].size();
     sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
     if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
     if (const char *e = getenv("RT355_PACKET_RAYS")) {

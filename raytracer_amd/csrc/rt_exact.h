@@ -16,6 +16,7 @@
 #define RT_OBJ_PLANE 0
 #define RT_OBJ_SPHERE 1
 #define RT_OBJ_MESH 2
+#define RT_OBJ_ENVIRONMENT 3
 
 struct d3 { double x, y, z; };
 
@@ -143,6 +144,21 @@ __device__ __forceinline__ double sphere_t_rec(const double4 &q, const Ray &e) {
     if (delta < 0) return -1;
     return B - (double)outside * sqrt(delta);
 }
+// Environment::CalcIntersect, anyobject.h:199-220, as every caller on the path reaches it: through an
+// AnyObject*, so the default argument is the base class's 0 (anyobject.h:23), or with an explicit 0
+// (shader.h:128,174).  `inside` is therefore 0 with the origin inside the sphere and -1 outside; t is the FAR
+// root.  q = (centre, radius).
+__device__ __forceinline__ double environment_t_rec(const double4 &q, const Ray &e, int *inside_out) {
+    d3 c = D3(q.x, q.y, q.z);
+    double r = q.w;
+    d3 ec = vsub(e.pe, c);
+    *inside_out = (dot(ec, ec) - r * r >= 0.00001) ? -1 : 0;
+    double B = dot(e.npe, vsub(c, e.pe));
+    double Cc = dot(ec, ec) - r * r;
+    double delta = B * B - Cc;
+    if (delta < 0) return -1;
+    return B + sqrt(delta);
+}
 // Triangle::CalcIntersect, anyobject.h:475-522
 __device__ __forceinline__ double tri_t(const DTriangle &t, const Ray &e, int *outside_out, d3 *ph_out,
                                         double *u_out, double *v_out) {
@@ -204,9 +220,9 @@ struct SceneView { // device pointers of an uploaded scene
                                // radius; for a triangle or plane the first 8 bytes hold (object, triangle)
     const DTexture *textures;
     const uint8_t *texels;
-    const int32_t *kind_prims; // the primitives sorted by kind: n_planes planes, n_spheres spheres, then the
-                               // triangles of all meshes, each kind in scene-list order
-    int32_t n_objects, n_prims, n_planes, n_spheres;
+    const int32_t *kind_prims; // the primitives sorted by kind: n_planes planes, n_spheres spheres, n_envs
+                               // environments, then the triangles of all meshes, each kind in scene-list order
+    int32_t n_objects, n_prims, n_planes, n_spheres, n_envs;
 };
 
 __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray &e, int *is_mesh, int *obj_out) {
@@ -222,6 +238,7 @@ __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray
     const DObject &o = s.objects[obj];
     if (o.type == RT_OBJ_PLANE) return plane_t(o, e);
     int outside;
+    if (o.type == RT_OBJ_ENVIRONMENT) return environment_t_rec(make_double4(o.p[0], o.p[1], o.p[2], o.radius), e, &outside);
     return sphere_t(o, e, &outside);
 }
 
@@ -250,10 +267,18 @@ __device__ __forceinline__ void closest_by_kind(const SceneView &s, const Ray &e
             consider(sphere_t_rec(s.prim_rec[prim], e), prim);
             if (ANY && bprim >= 0) break;
         }
-    if (!(ANY && bprim >= 0) && s.n_planes + s.n_spheres < s.n_prims) {
+    const int first_tri = s.n_planes + s.n_spheres + s.n_envs;
+    if (!(ANY && bprim >= 0))
+        for (k = s.n_planes + s.n_spheres; k < first_tri; k++) {
+            const int prim = s.kind_prims[k];
+            int inside;
+            consider(environment_t_rec(s.prim_rec[prim], e, &inside), prim);
+            if (ANY && bprim >= 0) break;
+        }
+    if (!(ANY && bprim >= 0) && first_tri < s.n_prims) {
         Closest c;
         c.init(POSITIVE ? 1 : 0);
-        for (k = s.n_planes + s.n_spheres; k < s.n_prims; k++) {
+        for (k = first_tri; k < s.n_prims; k++) {
             const int prim = s.kind_prims[k];
             int outside; d3 ph; double u, v;
             const double t = tri_t(s.tris[s.prim_tri[prim]], e, &outside, &ph, &u, &v);
@@ -301,7 +326,7 @@ __device__ __forceinline__ void texture_mapping(const SceneView &s, const DObjec
                                                 double uvy, uint32_t *cm0, uint32_t *cm1) {
     const DTexture &t0 = s.textures[o.tex0];
     const DTexture &t1 = s.textures[o.tex1];
-    if (o.type == RT_OBJ_SPHERE) {
+    if (o.type == RT_OBJ_SPHERE || o.type == RT_OBJ_ENVIRONMENT) { // shader.h:198
         d3 c = ld3(o.p);
         double x = dot(ld3(o.n0), vsub(ph, c)) / o.radius;
         double y = dot(ld3(o.n1), vsub(ph, c)) / o.radius;

@@ -97,6 +97,13 @@ public:
     const std::string GetObjectType() const override { return "Sphere"; }
 };
 
+class Environment : public Sphere { // anyobject.h:171-225: the constructor normalises the axes (:185-187)
+public:
+    Environment(Point3D c, double r, Color clr_in, Vector3D n0_in, Vector3D n1_in, Vector3D n2_in, double ks_in = 0)
+        : Sphere(c, r, clr_in, Normalize(n0_in), Normalize(n1_in), Normalize(n2_in), ks_in) {}
+    const std::string GetObjectType() const override { return "Environment"; }
+};
+
 struct Triangle { // anyobject.h:444-532 (data members only)
     Point3D p0, p1, p2; Vector2D UV_p0, UV_p1, UV_p2; // (0, 0) until SetUV, as the reference's members are
     Triangle(Point3D a, Point3D b, Point3D c) : p0(a), p1(b), p2(c) {}
@@ -208,7 +215,8 @@ public:
                 q.type = RT355_OBJ_PLANE; detail::put(q.p, p->pi); detail::put(q.n, p->ni); detail::put(q.n0, p->n0);
                 detail::put(q.rgb, p->clr);
             } else if (auto s = dynamic_cast<const Sphere *>(a)) {
-                q.type = RT355_OBJ_SPHERE; detail::put(q.p, s->pCenter); q.radius = s->radius;
+                q.type = dynamic_cast<const Environment *>(a) ? RT355_OBJ_ENVIRONMENT : RT355_OBJ_SPHERE;
+                detail::put(q.p, s->pCenter); q.radius = s->radius;
                 detail::put(q.n0, s->n0); detail::put(q.n1, s->n1); detail::put(q.n2, s->n2); detail::put(q.rgb, s->clr);
             } else if (auto m = dynamic_cast<const Mesh *>(a)) {
                 q.type = RT355_OBJ_MESH; detail::put(q.rgb, m->clr);

@@ -283,8 +283,33 @@ def small_case(name: str):
         for o, ks in zip(s.objects, (0.0, 0.35, 0.8, 0.5, 0.5, 0.5)):
             o["ks"] = ks
         return s, sh, default_camera(w, h), w, h
+    if name == "environment":
+        # a floor, a matt and a mirror sphere under a textured sky (the Environment of main.cpp:591-595, which HEAD
+        # constructs and leaves out of the list): sky seen directly, in the mirror, and by the shadow rays
+        w, h = 160, 120
+        s = Scene()
+        s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230), ks=0.2)
+        s.add_sphere((-10.5, 0, 0), 10, (100, 200, 100))
+        s.add_sphere((10.5, 0, 0), 10, (200, 100, 100), ks=0.6)
+        env = s.add_environment((0, -50, 20), 1000, (255, 255, 0), (-1, 1, 0), (-1, -1, 0), (0, 0, 1))
+        s.add_texture(env, _small_texture(64, 32, 51), 1, 1); s.add_texture(env, _small_texture(64, 32, 52), 1, 1)
+        s.set_texture_type(env, 1)
+        return s, default_shader(2), default_camera(w, h), w, h
+    if name == "environment_spheres":
+        # enough spheres to be searched, some of them mirrors, inside a flat-coloured Environment listed FIRST
+        # (so that rays that miss everything else still end on object 0 -- and chains go on with its ks)
+        w, h = 128, 96
+        s = Scene()
+        s.add_environment((0, 60, 10), 400, (90, 140, 230), ks=0.3)
+        sp = spheres_scene(150, seed=79)
+        for i, o in enumerate(sp.objects):
+            if i % 4 == 1:
+                o["ks"] = 0.7
+        s.objects.extend(sp.objects)
+        return s, Shader(ring_lights(3), 0x101010, 0xDDDDDD, 0x202020), default_camera(w, h), w, h
     raise KeyError(name)
 
 
 SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
-               "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside", "mirrors", "mirrors_mesh"]
+               "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside", "mirrors", "mirrors_mesh",
+               "environment", "environment_spheres"]

@@ -467,6 +467,49 @@ def test_random_scenes_with_mirrors(api, oracle, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(30, 38))
+def test_random_scenes_inside_an_environment(api, oracle, seed):
+    """The random scenes inside an Environment (anyobject.h:171-225, the sphere seen from within, unlit:
+    shader.h:70-72): placed first or last in the list, textured or flat, reflective or not, with and without
+    other mirrors, the eye inside it; shadow rays of lights inside it always end on it or before it, those of
+    directional lights too.  Searched (PACKET, ALLPAIRS) and unsearched (BRUTE) paths against the checker, the
+    gather shaders on the odd seeds."""
+    sc, sh, cam, w, h = _random_case(seed)
+    rng = S.SplitMix64(4242 + seed)
+    env = sc.add_environment((rng.uniform(-5, 5), rng.uniform(0, 20), rng.uniform(-5, 5)), rng.uniform(150, 900),
+                             (int(rng.uniform(30, 255)), int(rng.uniform(30, 255)), 240),
+                             (rng.uniform(-1, 1), 1, 0), (0, rng.uniform(-1, 1), 1), (1, 0, rng.uniform(-1, 1)),
+                             ks=(0.0, 0.5)[seed % 2])
+    if seed % 4 < 2:
+        sc.add_texture(env, S._small_texture(32, 16, seed), 1, 1)
+        if seed % 4 == 1:
+            sc.add_texture(env, S._small_texture(16, 16, seed + 1), 1, 1)
+            sc.set_texture_type(env, 1)
+    if seed % 3 == 0:      # the environment as object 0: rays that miss everything still end on it
+        sc.objects.insert(0, sc.objects.pop())
+    if seed >= 34:
+        for i, o in enumerate(sc.objects):
+            if i % 5 == 2:
+                o["ks"] = 0.6
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    r = api.Renderer(sc)
+    for mode in (B.MODE_PACKET, B.MODE_ALLPAIRS, B.MODE_BRUTE):
+        got, st = r.render(cam, sh, w, h, mode=mode)
+        _compare(got, want)
+        assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"], mode
+    if seed % 2:
+        dirs = B.geodesic(B.icosphere(0))
+        r.set_directions(dirs)
+        shading = (B.SHADING_BLEED, B.SHADING_OCCLUSION)[(seed // 2) % 2]
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=2, seed=seed, shading=shading), threads=0, dirs=dirs)
+        for mode in (B.MODE_PACKET, B.MODE_BRUTE):
+            got, st = r.render(cam, sh, w, h, alias=2, seed=seed, shading=shading, mode=mode)
+            _compare(got, want)
+            assert st["gather_rays"] == wst["gather_rays"]
+    r.close()
+
+
+@pytest.mark.gpu
 def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
     """CalcSubPixel2 with shading3 / shading2 (main.cpp:163-209, shader.h:100-191), HEAD's renderer: frames
     the reference's own shader code produced (fixtures), then more cases against the CPU checker, ray counts
