@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
 // the candidates are walked once more without it; two such meshes send the ray to the ordered walk over
 // everything (as does a ray whose candidates did not fit its own slots AND the bundle's spill list).
 // POSITIVE: the gather loops' rule, an object's hit counts only with t > 0 (shader.h:130,176).
-template <bool POSITIVE = false>
+template <bool POSITIVE = false, bool ENV = true>
 __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                             uint32_t n_rays, const uint32_t *__restrict__ cand,
                                             const uint32_t *__restrict__ cand_cnt, const Spill &sp, Closest &c,
@@ -1412,7 +1412,7 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
             auto consider = [&](uint32_t id, const double4 &rec) {
                 const int prim = (int)(id & CAND_INDEX);
                 double t; int obj = -1;
-                if ((id & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
+                if (ENV && (id & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
                     int inside;
                     t = environment_t_rec(rec, e, &inside);
                 } else if (id & CAND_SPHERE) {
@@ -1459,7 +1459,7 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
     }
     if (brute) {
         c.init();
-        closest_by_kind<POSITIVE, false>(s, e, c.t_best, c.prim_best);
+        closest_by_kind<POSITIVE, false, ENV>(s, e, c.t_best, c.prim_best);
         n = (uint32_t)s.n_prims;
     }
     evaluated += n;
@@ -1599,6 +1599,7 @@ struct HitGeo {
     double uvx, uvy;
     int obj;
 };
+template <bool ENV = true>
 __device__ __forceinline__ HitGeo hit_geometry(const SceneView &s, const Ray &e, const Closest &c) {
     HitGeo h;
     h.obj = s.prim_obj[c.prim_best];
@@ -1618,7 +1619,7 @@ __device__ __forceinline__ HitGeo hit_geometry(const SceneView &s, const Ray &e,
         int outside = (dot(ni, vsub(e.pe, ld3(o.p))) <= 0) ? -1 : 1; // anyobject.h:71-77
         h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // :85
         h.nh = vmul(ni, (double)outside);                            // :86
-    } else if (o.type == RT_OBJ_ENVIRONMENT) {
+    } else if (ENV && o.type == RT_OBJ_ENVIRONMENT) {
         int inside;
         environment_t_rec(make_double4(o.p[0], o.p[1], o.p[2], o.radius), e, &inside);
         h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // anyobject.h:215
@@ -1641,15 +1642,16 @@ struct HitRec {
     bool no_border;
     bool emissive; // an Environment: Shader::shading returns its (textured) colour before the lights (shader.h:70-72)
 };
+template <bool ENV = true>
 __device__ __forceinline__ HitRec primary_record(const SceneView &s, const ShaderView &sh, const Ray &e, const Closest &c) {
-    const HitGeo g = hit_geometry(s, e, c);
+    const HitGeo g = hit_geometry<ENV>(s, e, c);
     HitRec h;
     h.obj = g.obj; h.ph = g.ph; h.nh = g.nh;
     const DObject &o = s.objects[h.obj];
     h.cm0 = o.rgb; h.cm1 = sh.ambient;
     if (o.texture_type == 1) texture_mapping(s, o, h.ph, g.uvx, g.uvy, &h.cm0, &h.cm1); // shader.h:53-58
     h.no_border = (o.type == RT_OBJ_PLANE || o.type == RT_OBJ_MESH); // main.cpp:74
-    h.emissive = (o.type == RT_OBJ_ENVIRONMENT);
+    h.emissive = ENV && (o.type == RT_OBJ_ENVIRONMENT);
     h.reh = mirror_dir(h.nh, e.npe);
     h.border_w = h.no_border ? 0.0 : border_weight(e.pe, h.ph, h.nh);
     return h;
@@ -1684,8 +1686,9 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
 // REFLECT: the reflection recursion of CalcSubPixel (main.cpp:93-112) as a loop over at most four rays per
 // pixel (REFLECTION_TIMES_THRES 3, REFLECTION_KTOTAL_THRES 0.05, main.cpp:27-28), colours folded back from the
 // deepest.  On a miss the reference goes on with objs[0]'s ks, a zero hit point and a zero normal; so does
-// this.  Compiled apart so that scenes without mirrors do not carry the loop.
-template <bool REFLECT>
+// this.  Compiled apart so that scenes without mirrors do not carry the loop, and (ENV) scenes without an
+// Environment not its tests.
+template <bool REFLECT, bool ENV>
 __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                        unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1709,19 +1712,19 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
         if (!alive) continue;
         deepest = level;
         Closest c;
-        closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
+        closest_hit<false, ENV>(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
         uint32_t sum = 0u; // main.cpp:83: no hit -> Color(0,0,0); no lights -> clr_sum = (0,0,0), shader.h:49,95
         d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
         int obj = 0;
         if (c.prim_best >= 0) {
             if (level == 0) n_hit = 1;
-            const HitRec h = primary_record(s, sh, e, c);
+            const HitRec h = primary_record<ENV>(s, sh, e, c);
             ph = h.ph; nh = h.nh; obj = h.obj;
             if (h.emissive) sum = h.cm0;
             for (int k = 0; !h.emissive && k < sh.n_lights; k++)
                 sum = shade_light(sh, k, h, sum, [&](const Ray &sr) {
                     Closest o;
-                    closest_hit(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
+                    closest_hit<false, ENV>(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
                     return o.t_best;
                 }, n_shadow);
         }
@@ -3012,10 +3015,13 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             if (few) LAUNCH_GATHER(false, GATHER_FEW); else LAUNCH_GATHER(false, 0);
         }
 #undef LAUNCH_GATHER
-        else if (sc->reflective)
-            hipLaunchKernelGGL(k_render_direct<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
-        else
-            hipLaunchKernelGGL(k_render_direct<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+#define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
+        else if (sc->reflective) {
+            if (sc->view.n_envs > 0) LAUNCH_DIRECT(true, true); else LAUNCH_DIRECT(true, false);
+        } else {
+            if (sc->view.n_envs > 0) LAUNCH_DIRECT(false, true); else LAUNCH_DIRECT(false, false);
+        }
+#undef LAUNCH_DIRECT
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
     }
     int resolves = 0;

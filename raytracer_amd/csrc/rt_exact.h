@@ -248,7 +248,8 @@ __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray
 // spheres are objects of their own; the triangles arrive in list order and go through Closest, which keeps
 // the mesh rules.  POSITIVE: hits need t > 0 (gather rays, shader.h:130,176), else t >= 0.  ANY: stop at
 // the first hit found, whichever it is (shading2 only asks whether there is one, shader.h:130-133).
-template <bool POSITIVE, bool ANY>
+// ENV = false: the caller knows that the scene holds no Environment (its loop is compiled out).
+template <bool POSITIVE, bool ANY, bool ENV = true>
 __device__ __forceinline__ void closest_by_kind(const SceneView &s, const Ray &e, double &t_best, int &prim_best) {
     double bt = RT_FLT_MAX;
     int bprim = -1;
@@ -267,8 +268,8 @@ __device__ __forceinline__ void closest_by_kind(const SceneView &s, const Ray &e
             consider(sphere_t_rec(s.prim_rec[prim], e), prim);
             if (ANY && bprim >= 0) break;
         }
-    const int first_tri = s.n_planes + s.n_spheres + s.n_envs;
-    if (!(ANY && bprim >= 0))
+    const int first_tri = s.n_planes + s.n_spheres + (ENV ? s.n_envs : 0);
+    if (ENV && !(ANY && bprim >= 0))
         for (k = s.n_planes + s.n_spheres; k < first_tri; k++) {
             const int prim = s.kind_prims[k];
             int inside;
