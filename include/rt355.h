@@ -54,7 +54,9 @@ typedef struct rt355_object {
     double fresnel;   /* AnyObject::fresnel (:21); must be 1 (no refraction yet)             */
     double ior;       /* AnyObject::IOR (:20); carried, unused while fresnel == 1            */
     int32_t type;     /* RT355_OBJ_*                                                         */
-    int32_t texture_type; /* AnyObject::texture_type (:29): 0 flat colour, 1 texture mapping */
+    int32_t texture_type; /* AnyObject::texture_type (:29): 0 flat colour, 1 texture mapping (shader.h:53-58),
+                             2 solid texture: textures[0] and [1] projected along textures[0]'s n2
+                             (shader.h:59-63,296-319), 3 the 3D function of texture.h:164-177 (shader.h:64-68) */
     int32_t tex0;     /* index of textures[0] (lit colour map)  or -1                        */
     int32_t tex1;     /* index of textures[1] (dark colour map) or -1                        */
     int32_t tri_begin;/* Mesh: first triangle in rt355_scene_desc::triangles                 */
@@ -77,6 +79,10 @@ typedef struct rt355_texture {
     const uint8_t *rgb;
     double sx, sy;      /* Texture::sx, sy (texture.h:28-29) */
     int32_t width, height;
+    /* The projector's frame, read by texture_type 2 only (texture.h:32-35): AnyObject::AddTexture leaves
+     * it at n0 = (1,0,0), n1 = (0,1,0), n2 = (0,0,1), p_center = (0,0,0).  The library derives p00 as
+     * the Texture ctor does (texture.h:45). */
+    double n0[3], n1[3], n2[3], p_center[3];
 } rt355_texture;
 
 typedef struct rt355_scene_desc {

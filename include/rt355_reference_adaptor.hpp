@@ -81,6 +81,7 @@ inline Rt355Flattened rt355_flatten(const std::vector<AnyObject *> &objs,
             const Texture *t = a->textures[k];
             rt355_texture q;
             q.rgb = texels(t); q.sx = t->sx; q.sy = t->sy; q.width = t->width; q.height = t->height;
+            put(q.n0, t->n0); put(q.n1, t->n1); put(q.n2, t->n2); put(q.p_center, t->p_center); // texture.h:32-35
             (k == 0 ? o.tex0 : o.tex1) = (int32_t)f.textures.size();
             f.textures.push_back(q);
         }

@@ -157,8 +157,15 @@ bool build(const rt355_scene_desc *d, const char *tmpdir, RefScene &rs) {
         obj->fresnel = o.fresnel;
         obj->IOR = o.ior;
         obj->texture_type = o.texture_type;
-        if (o.tex0 >= 0) obj->AddTexture(tex_paths[o.tex0], d->textures[o.tex0].sx, d->textures[o.tex0].sy);
-        if (o.tex1 >= 0) obj->AddTexture(tex_paths[o.tex1], d->textures[o.tex1].sx, d->textures[o.tex1].sy);
+        for (int id : {o.tex0, o.tex1}) {
+            if (id < 0) continue;
+            const rt355_texture &t = d->textures[id];
+            static const double unit[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+            const bool plain = !memcmp(t.n0, unit, 24) && !memcmp(t.n1, unit + 3, 24) && !memcmp(t.n2, unit + 6, 24) &&
+                               !memcmp(t.p_center, zero, 24);
+            if (plain) obj->AddTexture(tex_paths[id], t.sx, t.sy); // anyobject.h:32-35
+            else obj->textures.push_back(new Texture(tex_paths[id], t.sx, t.sy, vec(t.n0), vec(t.n1), vec(t.n2), pnt(t.p_center)));
+        }
         rs.objs.push_back(obj);
         rs.kinds.push_back(o.type);
     }
@@ -461,6 +468,7 @@ int ref_adaptor_roundtrip(const rt355_scene_desc *d, const rt355_shader *sh, con
         if (a.tex0 >= 0) {
             const rt355_texture &ta = d->textures[a.tex0], &tb = f.textures[b.tex0];
             if (ta.width != tb.width || ta.height != tb.height || ta.sx != tb.sx || ta.sy != tb.sy || ta.rgb != tb.rgb) return 10 + i;
+            if (memcmp(ta.n0, tb.n0, 96)) return 10 + i; // n0, n1, n2, p_center
         }
     }
     if (d->n_triangles && memcmp(d->triangles, f.triangles.data(), sizeof(rt355_triangle) * d->n_triangles)) return 3;

@@ -276,6 +276,33 @@ static void texture_mapping(const oscene *s, const rt355_object *o, v3 ph, doubl
     }
 }
 
+/* Shader::SolidTexture, shader.h:296-319; p00 as the Texture ctor derives it, texture.h:45 */
+static void solid_texture(const oscene *s, const rt355_object *o, v3 ph, col ambient, col *cm0, col *cm1) {
+    const rt355_texture *t0 = &s->d->textures[o->tex0], *t1 = &s->d->textures[o->tex1];
+    v3 n0 = from3(t0->n0), n1 = from3(t0->n1), n2 = from3(t0->n2), pc = from3(t0->p_center);
+    v3 p00 = vsub(vsub(pc, vmul(n0, t0->sx / 2)), vmul(n1, t0->sy / 2));
+    double t = dot(vsub(ph, pc), n2);
+    v3 pp = vsub(ph, vmul(n2, t));
+    double x = dot(vsub(pp, p00), n0) / t0->sx;
+    double y = dot(vsub(pp, p00), n1) / t0->sy;
+    if (x > 0 && x < 1 && y > 0 && y < 1) {
+        *cm0 = tex_plane(t0, x, y);
+        *cm1 = tex_plane(t1, x, y);
+    } else {
+        *cm1 = ambient;
+    }
+}
+/* Texture::Get3DFunction, texture.h:164-177, with the centre shader.h:66 passes */
+static col function_3d(v3 ph) {
+    v3 v = vsub(ph, V(0, 0, 20));
+    v3 u = V(v.x, 0, v.z);
+    double f = vlen(cross(u, V(1, 0, 0))) + dot(u, V(1, 0, 0));
+    f = sin(f * REF_PI * 0.3); /* only the sign is used: any libm will do */
+    double T = 0;
+    if (f - T > 0) return C(250, 235, 190);
+    return C(90, 190, 250);
+}
+
 /* ---- shader.h --------------------------------------------------------------------------------- */
 typedef struct {
     const oscene *s;
@@ -338,6 +365,8 @@ static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_bor
     const rt355_shader *sh = cx->sh;
     col clr_sum = C(0, 0, 0);
     if (o->texture_type == 1) texture_mapping(cx->s, o, ph, uvx, uvy, &cm0, &cm1);
+    else if (o->texture_type == 2) solid_texture(cx->s, o, ph, cm1, &cm0, &cm1); /* shader.h:59-63 */
+    else if (o->texture_type == 3) cm0 = function_3d(ph);                        /* :64-68; cm1 is the ambient colour already */
     if (o->type == RT355_OBJ_ENVIRONMENT) return cm0; /* shader.h:70-72 */
     for (int k = 0; k < sh->n_lights; k++) {
         const rt355_light *L = &sh->lights[k];

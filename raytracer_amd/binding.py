@@ -44,7 +44,8 @@ LIGHT_DTYPE = np.dtype(
 
 class CTexture(C.Structure):
     _fields_ = [("rgb", C.c_void_p), ("sx", C.c_double), ("sy", C.c_double),
-                ("width", C.c_int32), ("height", C.c_int32)]
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("n0", C.c_double * 3), ("n1", C.c_double * 3), ("n2", C.c_double * 3), ("p_center", C.c_double * 3)]
 
 
 class CSceneDesc(C.Structure):
@@ -79,7 +80,7 @@ class CStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-assert C.sizeof(CTexture) == 32 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
+assert C.sizeof(CTexture) == 128 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
 assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 32 and C.sizeof(CStats) == 80
 
 
@@ -106,6 +107,11 @@ class Texture:
     rgb: np.ndarray
     sx: float = 1.0
     sy: float = 1.0
+    # the projector's frame of a solid texture (texture.h:32-35), the defaults of the Texture ctor
+    n0: tuple = (1.0, 0.0, 0.0)
+    n1: tuple = (0.0, 1.0, 0.0)
+    n2: tuple = (0.0, 0.0, 1.0)
+    p_center: tuple = (0.0, 0.0, 0.0)
 
 
 @dataclass
@@ -165,12 +171,16 @@ class Scene:
         self.objects.append(o)
         return len(self.objects) - 1
 
-    def add_texture(self, obj: int, rgb: np.ndarray, sx=1.0, sy=1.0):
+    def add_texture(self, obj: int, rgb: np.ndarray, sx=1.0, sy=1.0, frame=None):
         """AnyObject::AddTexture (anyobject.h:32-35); the first call sets textures[0], the
-        second textures[1]."""
+        second textures[1].  frame = (n0, n1, n2, p_center): a Texture constructed with its projector
+        (texture.h:42) and pushed onto AnyObject::textures directly, for texture_type 2."""
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         assert rgb.ndim == 3 and rgb.shape[2] == 3
-        self.textures.append(Texture(rgb, float(sx), float(sy)))
+        t = Texture(rgb, float(sx), float(sy))
+        if frame is not None:
+            t.n0, t.n1, t.n2, t.p_center = (tuple(float(c) for c in v) for v in frame)
+        self.textures.append(t)
         tid = len(self.textures) - 1
         o = self.objects[obj]
         if o["tex0"] < 0:
@@ -205,6 +215,8 @@ class PackedScene:
         for i, t in enumerate(s.textures):
             self.ctex[i].rgb = self.tex_arrays[i].ctypes.data
             self.ctex[i].sx, self.ctex[i].sy = t.sx, t.sy
+            self.ctex[i].n0[:], self.ctex[i].n1[:], self.ctex[i].n2[:] = t.n0, t.n1, t.n2
+            self.ctex[i].p_center[:] = t.p_center
             self.ctex[i].height, self.ctex[i].width = t.rgb.shape[0], t.rgb.shape[1]
         d = CSceneDesc()
         d.objects = self.objects.ctypes.data if len(self.objects) else None

@@ -39,7 +39,7 @@
 #include "../../include/rt355.h"
 #include "rt_exact.h"
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 #define SEARCH_THREADS 256
 #ifndef RAYS_PER_THREAD
 #define RAYS_PER_THREAD 4   // rays per lane of the search kernel (2, 4 or 8)
@@ -1650,6 +1650,8 @@ __device__ __forceinline__ HitRec primary_record(const SceneView &s, const Shade
     const DObject &o = s.objects[h.obj];
     h.cm0 = o.rgb; h.cm1 = sh.ambient;
     if (o.texture_type == 1) texture_mapping(s, o, h.ph, g.uvx, g.uvy, &h.cm0, &h.cm1); // shader.h:53-58
+    else if (o.texture_type == 2) solid_texture(s, o, h.ph, sh.ambient, &h.cm0, &h.cm1); // :59-63
+    else if (o.texture_type == 3) h.cm0 = function_3d(h.ph);                             // :64-68 (cm1 = ambient)
     h.no_border = (o.type == RT_OBJ_PLANE || o.type == RT_OBJ_MESH); // main.cpp:74
     h.emissive = ENV && (o.type == RT_OBJ_ENVIRONMENT);
     h.reh = mirror_dir(h.nh, e.npe);
@@ -2535,10 +2537,12 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
             return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": fresnel != 1 (refraction, main.cpp:116-154, is not accelerated)");
         if (o.ks != 0) any_ks = true;
         ks_abs_max = std::max(ks_abs_max, std::isfinite(o.ks) ? fabs(o.ks) : 1e300);
-        if (o.texture_type != 0 && o.texture_type != 1)
-            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": texture_type 2/3 (solid / procedural) is not accelerated");
-        if (o.texture_type == 1 && (o.tex0 < 0 || o.tex1 < 0 || o.tex0 >= d->n_textures || o.tex1 >= d->n_textures))
+        if (o.texture_type < 0 || o.texture_type > 3)
+            return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": texture_type is 0, 1, 2 or 3 (anyobject.h:27-29)");
+        if ((o.texture_type == 1 || o.texture_type == 2) && (o.tex0 < 0 || o.tex1 < 0 || o.tex0 >= d->n_textures || o.tex1 >= d->n_textures))
             return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": texture mapping needs textures[0] and textures[1]");
+        if (o.texture_type == 3 && (o.tex0 < 0 || o.tex0 >= d->n_textures)) // shader.h:66 calls through textures[0]
+            return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": texture_type 3 needs textures[0]");
         DObject &q = objs[i];
         memset(&q, 0, sizeof q);
         memcpy(q.p, o.p, sizeof q.p); memcpy(q.n, o.n, sizeof q.n);
@@ -2591,6 +2595,10 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         const rt355_texture &t = d->textures[i];
         if (!t.rgb || t.width <= 0 || t.height <= 0) return fail(RT355_ERR_ARG, "texture " + std::to_string(i) + ": empty");
         tex[i].offset = pool.size(); tex[i].sx = t.sx; tex[i].sy = t.sy; tex[i].width = t.width; tex[i].height = t.height;
+        memcpy(tex[i].n0, t.n0, sizeof t.n0); memcpy(tex[i].n1, t.n1, sizeof t.n1); memcpy(tex[i].n2, t.n2, sizeof t.n2);
+        memcpy(tex[i].p_center, t.p_center, sizeof t.p_center);
+        for (int a = 0; a < 3; a++) // p00 = p_center - n0 * (sx / 2) - n1 * (sy / 2), texture.h:45
+            tex[i].p00[a] = t.p_center[a] - t.n0[a] * (t.sx / 2) - t.n1[a] * (t.sy / 2);
         pool.insert(pool.end(), t.rgb, t.rgb + (size_t)t.width * t.height * 3);
     }
     std::vector<int32_t> kind_prims(by_kind[0]);

@@ -85,6 +85,7 @@ struct DTexture {
     uint64_t offset; // byte offset into the texel pool
     double sx, sy;
     int32_t width, height;
+    double n0[3], n1[3], n2[3], p_center[3], p00[3]; // the solid texture's projector (texture.h:32-37,44-45)
 };
 struct DLight {
     double position[3], direction[3], color[3];
@@ -358,6 +359,35 @@ __device__ __forceinline__ void texture_mapping(const SceneView &s, const DObjec
         *cm0 = tex_plane(t0, s.texels, uvx, uvy);
         *cm1 = tex_plane(t1, s.texels, uvx, uvy);
     }
+}
+
+// Shader::SolidTexture, shader.h:296-319: the hit point projected along textures[0]'s n2 onto its plane; both
+// maps are read with textures[0]'s frame, outside of it the object keeps its colour over the ambient one.
+__device__ __forceinline__ void solid_texture(const SceneView &s, const DObject &o, d3 ph, uint32_t ambient,
+                                              uint32_t *cm0, uint32_t *cm1) {
+    const DTexture &t0 = s.textures[o.tex0];
+    const d3 n2 = ld3(t0.n2);
+    const double t = dot(vsub(ph, ld3(t0.p_center)), n2);
+    const d3 pp = vsub(ph, vmul(n2, t));
+    const double x = dot(vsub(pp, ld3(t0.p00)), ld3(t0.n0)) / t0.sx;
+    const double y = dot(vsub(pp, ld3(t0.p00)), ld3(t0.n1)) / t0.sy;
+    if (x > 0 && x < 1 && y > 0 && y < 1) {
+        *cm0 = tex_plane(t0, s.texels, x, y);
+        *cm1 = tex_plane(s.textures[o.tex1], s.texels, x, y);
+    } else {
+        *cm1 = ambient; // cm0 stays the colour CalcIntersect returned (shader.h:311)
+    }
+}
+// Texture::Get3DFunction(ph, Point3D(0, 0, 20)), texture.h:164-177 as shader.h:66 calls it: bands by the sign
+// of sin(0.3 pi (|v x (1,0,0)| + v . (1,0,0))), v = (ph - centre) without its y.  Only the sign of the sine is
+// used, and any sine with a relative error bound has the right sign (sin is zero at no double but 0).
+__device__ __forceinline__ uint32_t function_3d(d3 ph) {
+    const d3 v = vsub(ph, D3(0, 0, 20));
+    const d3 u = D3(v.x, 0, v.z), w = D3(1, 0, 0);
+    const d3 c = D3(u.y * w.z - u.z * w.y, u.z * w.x - u.x * w.z, u.x * w.y - u.y * w.x); // vector3D.h:94-96
+    double f = vlen(c) + dot(u, w);
+    f = sin(f * RT_PI * 0.3);
+    return (f - 0.0 > 0) ? RGB(250, 235, 190) : RGB(90, 190, 250);
 }
 
 #ifndef RT_POW25

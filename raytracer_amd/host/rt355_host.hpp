@@ -44,13 +44,18 @@ struct Color { // color.h:16-31
 
 struct Texture { // a loaded texture.h Texture: texels in memory order, scale factors
     std::vector<unsigned char> rgb; int width = 0, height = 0; double sx = 1, sy = 1;
+    // the projector of a solid texture (texture.h:32-35); p00 and p_projector are derived from it by the library
+    Vector3D n0{1, 0, 0}, n1{0, 1, 0}, n2{0, 0, 1};
+    Point3D p_center{0, 0, 0};
     Texture() {}
     // Texture(string filename, double sx, double sy) of texture.h:42-79: a 54-byte header with the width at
     // byte 18 and the height at byte 22, then 3 * width * height bytes taken as they come (no row padding,
     // no bit-depth check, bottom row first), B and R swapped in place.  A file that cannot be opened is an
     // error here as it is there (`throw "Argument Exception"`, texture.h:52); a file shorter than its header
     // promises leaves the missing texels 0 (the reference leaves them uninitialised).
-    explicit Texture(const std::string &filename, double sx_in = 1, double sy_in = 1) : sx(sx_in), sy(sy_in) {
+    explicit Texture(const std::string &filename, double sx_in = 1, double sy_in = 1, Vector3D n0_in = {1, 0, 0},
+                     Vector3D n1_in = {0, 1, 0}, Vector3D n2_in = {0, 0, 1}, Point3D p_center_in = {0, 0, 0})
+        : sx(sx_in), sy(sy_in), n0(n0_in), n1(n1_in), n2(n2_in), p_center(p_center_in) {
         FILE *fp = std::fopen(filename.c_str(), "rb");
         if (!fp) throw Error("cannot open texture " + filename);
         unsigned char info[54];
@@ -234,6 +239,7 @@ public:
             for (size_t k = 0; k < a->textures.size() && k < 2; k++) {
                 const Texture &tx = *a->textures[k];
                 rt355_texture r; r.rgb = tx.rgb.data(); r.sx = tx.sx; r.sy = tx.sy; r.width = tx.width; r.height = tx.height;
+                detail::put(r.n0, tx.n0); detail::put(r.n1, tx.n1); detail::put(r.n2, tx.n2); detail::put(r.p_center, tx.p_center);
                 (k == 0 ? q.tex0 : q.tex1) = (int32_t)x.size();
                 x.push_back(r);
             }

@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-from .binding import OBJECT_DTYPE, OBJ_SPHERE, Scene, Shader, camera, light_src
+from .binding import OBJECT_DTYPE, OBJ_SPHERE, Scene, Shader, camera, light_src, _normalize as _n
 
 _M64 = (1 << 64) - 1
 
@@ -307,9 +307,41 @@ def small_case(name: str):
                 o["ks"] = 0.7
         s.objects.extend(sp.objects)
         return s, Shader(ring_lights(3), 0x101010, 0xDDDDDD, 0x202020), default_camera(w, h), w, h
+    if name == "solid_texture":
+        # texture_type 2 (shader.h:59-63,296-319): two maps projected along a tilted axis onto a sphere, the back
+        # wall and a mesh; outside the projector's rectangle the objects keep their own colour.  The second sphere uses
+        # the frame AnyObject::AddTexture leaves (projection along z about the origin).
+        w, h = 160, 120
+        s = default_scene()
+        frame = (_n((1, 0.2, 0)), _n((-0.1, 0.1, 1)), _n((0.1, -1, 0.2)), (-3.0, 0.0, 1.0))
+        for o, (sx, sy) in ((0, (70.0, 50.0)), (2, (24.0, 18.0))):
+            s.add_texture(o, _small_texture(32, 16, 61 + o), sx, sy, frame=frame)
+            s.add_texture(o, _small_texture(16, 16, 71 + o), sx, sy, frame=frame)
+            s.set_texture_type(o, 2)
+        s.add_texture(3, _small_texture(24, 24, 81), 12.0, 40.0); s.add_texture(3, _small_texture(8, 8, 82), 1, 1)
+        s.set_texture_type(3, 2)
+        m = s.add_mesh(heightfield_tris(6, 6, seed=5, x0=-20, x1=-6, y0=-6, y1=4, zbase=-8, amp=2.0), ks=0.3)
+        s.add_texture(m, _small_texture(16, 32, 91), 25.0, 25.0, frame=(_n((0, 1, 0)), _n((0, 0, 1)), _n((1, 0, 0)), (-13.0, 0.0, -6.0)))
+        s.add_texture(m, _small_texture(16, 32, 92), 1, 1)
+        s.set_texture_type(m, 2)
+        return s, default_shader(2), default_camera(w, h), w, h
+    if name == "function_3d":
+        # texture_type 3 (shader.h:64-68, texture.h:164-177), as main.cpp:586-588 sets it on sphere3: bands on the
+        # spheres, the floor and an Environment; textures[0] is only called through
+        w, h = 160, 120
+        s = default_scene()
+        for o in (1, 2, 3):
+            s.add_texture(o, _small_texture(8, 8, 17), 0.5, 0.5); s.add_texture(o, _small_texture(8, 8, 17), 0.5, 0.5)
+            s.set_texture_type(o, 3)
+        s.objects[3]["ks"] = 0.4
+        env = s.add_environment((0, 0, 0), 500, (40, 40, 90))
+        s.add_texture(env, _small_texture(8, 8, 18), 1, 1)
+        s.set_texture_type(env, 3)
+        del s.objects[0]   # the back wall: the sky behind the spheres
+        return s, default_shader(2), default_camera(w, h), w, h
     raise KeyError(name)
 
 
 SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
                "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside", "mirrors", "mirrors_mesh",
-               "environment", "environment_spheres"]
+               "environment", "environment_spheres", "solid_texture", "function_3d"]

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in rt355.h but not exported"
     L.rt355_abi_version.restype = ctypes.c_int
-    assert L.rt355_abi_version() >= 3
+    assert L.rt355_abi_version() >= 4
     # the exported jitter and its Python mirror
     from raytracer_amd import binding as B
     L.rt355_jitter.restype = ctypes.c_double

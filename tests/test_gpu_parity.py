@@ -312,6 +312,15 @@ def test_error_behaviour(api):
     with pytest.raises(api.Rt355Error, match="UNSUPPORTED"):
         api.Renderer(sc)
     sc = S.default_scene()
+    sc.set_texture_type(2, 4)
+    with pytest.raises(api.Rt355Error, match="texture_type"):
+        api.Renderer(sc)
+    for kind in (1, 2, 3):   # the reference dereferences textures[0] (and [1]) of such an object
+        sc = S.default_scene()
+        sc.set_texture_type(2, kind)
+        with pytest.raises(api.Rt355Error, match="needs textures"):
+            api.Renderer(sc)
+    sc = S.default_scene()
     r = api.Renderer(sc)
     with pytest.raises(api.Rt355Error, match="alias"):
         r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, alias=-1)
