@@ -39,6 +39,8 @@ extern "C" {
 #define RT355_OBJ_MESH   2
 #define RT355_OBJ_ENVIRONMENT 3 /* "Environment" anyobject.h:223: a sphere seen from inside whose (textured) colour
                                    Shader::shading returns unlit (shader.h:70-72); fields as for a Sphere */
+#define RT355_OBJ_QUADRIC 4     /* Quadric and its subclasses Cone, Ellipsoid, Cylinder, EllipticParaboloid,
+                                   HyperbolicParaboloid (anyobject.h:231-442), which differ in aCoor alone */
 
 /* One entry of Scene::objs (main.cpp:229).  Order is significant: the closest-hit loop
  * keeps the first object on equal t (main.cpp:68). */
@@ -61,8 +63,12 @@ typedef struct rt355_object {
     int32_t tex1;     /* index of textures[1] (dark colour map) or -1                        */
     int32_t tri_begin;/* Mesh: first triangle in rt355_scene_desc::triangles                 */
     int32_t tri_count;/* Mesh: number of triangles (Mesh::triangles, :541)                   */
-    uint8_t rgb[3];   /* the object's own `clr` (Plane :42, Sphere :100, Mesh :536)          */
+    uint8_t rgb[3];   /* the object's own `clr` (Plane :42, Sphere :100, Quadric :240, Mesh :536) */
     uint8_t pad_[5];
+    /* Quadric only (anyobject.h:233-239): p = pCenter, n0 / n1 / n2 = nCoor[0..2] as SetN stored them */
+    double s[3];      /* Quadric::sCoor (SetS takes floats, :265: pass the stored doubles)  */
+    int32_t a[5];     /* Quadric::aCoor = a02, a12, a22, a21, a00 (:234-235)                  */
+    int32_t pad2_;
 } rt355_object;
 
 /* One Triangle of a Mesh (anyobject.h:444-532).  The library derives `normal` and

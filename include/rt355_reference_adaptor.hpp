@@ -2,7 +2,8 @@
 //
 // Include AFTER the reference's own headers (vector3D.h, color.h, texture.h, shader.h,
 // anyobject.h): it walks a `vector<AnyObject*>` (Scene::objs, main.cpp:229), down-casts by
-// GetObjectType() ("Plane" anyobject.h:89, "Sphere" :161, "Environment" :223, "Mesh" :672) and fills the plain-C
+// GetObjectType() ("Plane" anyobject.h:89, "Sphere" :161, "Environment" :223, "Quadric" and its subclasses
+// :348-440, "Mesh" :672) and fills the plain-C
 // descriptors of rt355.h.  It holds no reference code, only member reads.
 //
 // Two members of the reference are private and cannot be read from outside:
@@ -60,6 +61,14 @@ inline Rt355Flattened rt355_flatten(const std::vector<AnyObject *> &objs,
             o.type = kind == "Sphere" ? RT355_OBJ_SPHERE : RT355_OBJ_ENVIRONMENT;
             put(o.p, s->pCenter); o.radius = s->radius;
             put(o.n0, s->n0); put(o.n1, s->n1); put(o.n2, s->n2); put(o.rgb, s->clr);
+        } else if (kind == "Quadric" || kind == "Cone" || kind == "Ellipsoid" || kind == "Cylinder" ||
+                   kind == "EllipticParaboloid" || kind == "HyperbolicParaboloid") { // anyobject.h:348,367,386,404,422,440
+            Quadric *q = (Quadric *)a;
+            o.type = RT355_OBJ_QUADRIC;
+            put(o.p, q->pCenter); put(o.n0, q->nCoor[0]); put(o.n1, q->nCoor[1]); put(o.n2, q->nCoor[2]);
+            for (int k = 0; k < 3; k++) o.s[k] = q->sCoor[k];
+            for (int k = 0; k < 5; k++) o.a[k] = q->aCoor[k];
+            put(o.rgb, q->clr); // Quadric::clr (:240), the one CalcIntersect returns
         } else if (kind == "Mesh") {
             Mesh *m = (Mesh *)a;
             o.type = RT355_OBJ_MESH;

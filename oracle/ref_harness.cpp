@@ -138,6 +138,25 @@ bool build(const rt355_scene_desc *d, const char *tmpdir, RefScene &rs) {
             Environment *env = new Environment(pnt(o.p), o.radius, clr, vec(o.n0), vec(o.n1), vec(o.n2), o.ks);
             env->n0 = vec(o.n0); env->n1 = vec(o.n1); env->n2 = vec(o.n2); // the descriptor holds the members as stored
             obj = env;
+        } else if (o.type == RT355_OBJ_QUADRIC) {
+            // a subclass where the coefficients are one's (anyobject.h:355-442), the general constructor otherwise
+            Quadric *q = nullptr;
+            auto is = [&](int a0, int a1, int a2, int a3, int a4) {
+                return o.a[0] == a0 && o.a[1] == a1 && o.a[2] == a2 && o.a[3] == a3 && o.a[4] == a4;
+            };
+            if (is(1, 1, -1, 0, 0)) q = new Cone();
+            else if (is(1, 1, 1, 0, -1)) q = new Ellipsoid();
+            else if (is(1, 1, 0, 0, -1)) q = new Cylinder();
+            else if (is(1, 1, 0, -1, 0)) q = new EllipticParaboloid();
+            else if (is(1, -1, 0, -1, 0)) q = new HyperbolicParaboloid();
+            else if (is(0, 0, 0, 1, 0)) q = new Quadric();
+            else q = new Quadric(o.a[0], o.a[1], o.a[2], o.a[3], o.a[4]);
+            q->SetPCenter(pnt(o.p));
+            q->SetN(vec(o.n0), vec(o.n1), vec(o.n2));
+            q->SetS(o.s[0], o.s[1], o.s[2]); // floats there (anyobject.h:265): the descriptor holds float values
+            q->SetColor(clr);
+            q->SetKs(o.ks);
+            obj = q;
         } else {
             std::cout.rdbuf(sink.rdbuf());
             Mesh *m = new Mesh("/nonexistent/rt355.obj", Point3D(0, 0, 0), 1, o.ks);
@@ -463,6 +482,7 @@ int ref_adaptor_roundtrip(const rt355_scene_desc *d, const rt355_shader *sh, con
         if (a.ks != b.ks || a.fresnel != b.fresnel || a.ior != b.ior) return 10 + i;
         if (a.type == RT355_OBJ_PLANE && (memcmp(a.p, b.p, 24) || memcmp(a.n, b.n, 24) || memcmp(a.n0, b.n0, 24))) return 10 + i;
         if ((a.type == RT355_OBJ_SPHERE || a.type == RT355_OBJ_ENVIRONMENT) && (memcmp(a.p, b.p, 24) || a.radius != b.radius || memcmp(a.n0, b.n0, 72))) return 10 + i;
+        if (a.type == RT355_OBJ_QUADRIC && (memcmp(a.p, b.p, 24) || memcmp(a.n0, b.n0, 72) || memcmp(a.s, b.s, 24) || memcmp(a.a, b.a, 20))) return 10 + i;
         if (a.type == RT355_OBJ_MESH && (a.tri_begin != b.tri_begin || a.tri_count != b.tri_count)) return 10 + i;
         if ((a.tex0 >= 0) != (b.tex0 >= 0) || (a.tex1 >= 0) != (b.tex1 >= 0)) return 10 + i;
         if (a.tex0 >= 0) {

@@ -155,6 +155,54 @@ static hit environment_isect(const rt355_object *o, ray e) {
     return h;
 }
 
+/* Quadric::CalcIntersect, anyobject.h:283-345, outside == 0 on entry.  The formulas are kept as written there
+ * (the divisions and powers repeated per call); pow(x, 2) is x * x.  In the A == 0 branch the reference's loop
+ * over the axes starts from an uninitialised index (`for (int i; ...`, :316): it is taken to run from 0 like its
+ * twin at :333, which is what the harness build (g++ -O2) does too. */
+static hit quadric_isect(const rt355_object *o, ray e) {
+    hit h; memset(&h, 0, sizeof h);
+    v3 pc = from3(o->p);
+    v3 n[3] = {from3(o->n0), from3(o->n1), from3(o->n2)};
+    const int32_t *a = o->a;
+    const double *s = o->s;
+    double Fp = a[3] / s[2] * dot(n[2], vsub(e.pe, pc)) + a[4];
+    for (int i = 0; i < 3; i++) { double v = dot(n[i], vsub(e.pe, pc)) / s[i]; Fp += a[i] * (v * v); }
+    int outside = (Fp < 0) ? -1 : 1;
+    double A = 0;
+    double B = a[3] / s[2] * dot(n[2], e.npe);
+    double C = a[3] / s[2] * dot(n[2], vsub(e.pe, pc)) + a[4];
+    for (int i = 0; i < 3; i++) {
+        double u = dot(n[i], e.npe) / s[i];
+        A += a[i] * (u * u);
+        B += 2 * a[i] / (s[i] * s[i]) * dot(n[i], e.npe) * dot(n[i], vsub(e.pe, pc));
+        double v = dot(n[i], vsub(e.pe, pc)) / s[i];
+        C += a[i] * (v * v);
+    }
+    if (A == 0) {
+        if (B != 0) {
+            h.t = -(C / B);
+            h.ph = vadd(e.pe, vmul(e.npe, h.t));
+            v3 nh = vmul(n[2], a[3] / s[2]);
+            for (int i = 0; i < 3; i++) nh = vadd(nh, vmul(n[i], 2 * a[i] / (s[i] * s[i]) * dot(n[i], vsub(h.ph, pc))));
+            h.nh = vmul(normalize(nh), outside);
+            return h;
+        }
+        h.t = -1;
+        return h;
+    }
+    double delta = B * B - 4 * A * C;
+    if (delta >= 0) {
+        h.t = (-B - sqrt(delta)) / (2 * A);
+        h.ph = vadd(e.pe, vmul(e.npe, h.t));
+        v3 nh = vmul(n[2], a[3] / s[2]);
+        for (int i = 0; i < 3; i++) nh = vadd(nh, vmul(n[i], 2 * a[i] / (s[i] * s[i]) * dot(n[i], vsub(h.ph, pc))));
+        h.nh = vmul(normalize(nh), outside);
+        return h;
+    }
+    h.t = -1;
+    return h;
+}
+
 /* Triangle::CalcIntersect, anyobject.h:475-522; u,v returned for GetUV (:524-526) */
 static hit tri_isect(const otri *t, ray e, double *u_out, double *v_out) {
     hit h; memset(&h, 0, sizeof h);
@@ -205,6 +253,7 @@ static hit obj_isect(const oscene *s, int i, ray e) {
     if (o->type == RT355_OBJ_PLANE) return plane_isect(o, e);
     if (o->type == RT355_OBJ_SPHERE) return sphere_isect(o, e);
     if (o->type == RT355_OBJ_ENVIRONMENT) return environment_isect(o, e);
+    if (o->type == RT355_OBJ_QUADRIC) return quadric_isect(o, e);
     return mesh_isect(s, o, e);
 }
 
@@ -240,6 +289,7 @@ static col tex_plane(const rt355_texture *t, double x, double y) {        /* tex
 /* Shader::TextureMapping, shader.h:196-288 (normal map off, shader.h:23) */
 static void texture_mapping(const oscene *s, const rt355_object *o, v3 ph, double uvx, double uvy,
                             col *cm0, col *cm1) {
+    if (o->type == RT355_OBJ_QUADRIC) { *cm0 = C(0, 0, 0); *cm1 = C(0, 0, 0); return; } /* no branch of shader.h:198-285: Color() */
     const rt355_texture *t0 = &s->d->textures[o->tex0], *t1 = &s->d->textures[o->tex1];
     if (o->type == RT355_OBJ_SPHERE || o->type == RT355_OBJ_ENVIRONMENT) { /* shader.h:198 */
         v3 c = from3(o->p);

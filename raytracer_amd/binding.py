@@ -14,21 +14,25 @@ from typing import List, Sequence
 
 import numpy as np
 
-OBJ_PLANE, OBJ_SPHERE, OBJ_MESH, OBJ_ENVIRONMENT = 0, 1, 2, 3
+OBJ_PLANE, OBJ_SPHERE, OBJ_MESH, OBJ_ENVIRONMENT, OBJ_QUADRIC = 0, 1, 2, 3, 4
+# aCoor of Quadric's subclasses (anyobject.h:355-442) and of the default Quadric, "a plane" (:242-249)
+QUADRIC_KINDS = {"Quadric": (0, 0, 0, 1, 0), "Cone": (1, 1, -1, 0, 0), "Ellipsoid": (1, 1, 1, 0, -1),
+                 "Cylinder": (1, 1, 0, 0, -1), "EllipticParaboloid": (1, 1, 0, -1, 0),
+                 "HyperbolicParaboloid": (1, -1, 0, -1, 0)}
 MODE_ALLPAIRS, MODE_BRUTE, MODE_PACKET = 0, 1, 2
 SHADING_LIGHTS, SHADING_OCCLUSION, SHADING_BLEED = 0, 1, 2
 
 ERR = {0: "OK", -1: "ERR_ARG", -2: "ERR_UNSUPPORTED", -3: "ERR_DEVICE", -4: "ERR_NOMEM"}
 
-# struct rt355_object (184 bytes)
+# struct rt355_object (232 bytes)
 OBJECT_DTYPE = np.dtype(
     {
         "names": ["p", "n", "n0", "n1", "n2", "radius", "ks", "fresnel", "ior", "type",
-                  "texture_type", "tex0", "tex1", "tri_begin", "tri_count", "rgb", "pad_"],
+                  "texture_type", "tex0", "tex1", "tri_begin", "tri_count", "rgb", "pad_", "s", "a", "pad2_"],
         "formats": [("f8", 3), ("f8", 3), ("f8", 3), ("f8", 3), ("f8", 3), "f8", "f8", "f8", "f8",
-                    "i4", "i4", "i4", "i4", "i4", "i4", ("u1", 3), ("u1", 5)],
-        "offsets": [0, 24, 48, 72, 96, 120, 128, 136, 144, 152, 156, 160, 164, 168, 172, 176, 179],
-        "itemsize": 184,
+                    "i4", "i4", "i4", "i4", "i4", "i4", ("u1", 3), ("u1", 5), ("f8", 3), ("i4", 5), "i4"],
+        "offsets": [0, 24, 48, 72, 96, 120, 128, 136, 144, 152, 156, 160, 164, 168, 172, 176, 179, 184, 208, 228],
+        "itemsize": 232,
     }
 )
 # struct rt355_light (80 bytes)
@@ -156,6 +160,18 @@ class Scene:
         o = self._new(OBJ_ENVIRONMENT, clr, ks)
         o["p"] = center; o["radius"] = radius
         o["n0"] = _normalize(n0); o["n1"] = _normalize(n1); o["n2"] = _normalize(n2)
+        self.objects.append(o)
+        return len(self.objects) - 1
+
+    def add_quadric(self, kind, center, n0, n1, n2, s, clr, ks=0.0):
+        """A Quadric or one of its subclasses (anyobject.h:231-442) after SetPCenter, SetN, SetS, SetColor and
+        SetKs: kind is a class name of QUADRIC_KINDS or the five aCoor themselves.  SetS takes floats
+        (anyobject.h:265), so the scales are rounded to float as they are there; SetN stores the axes as given."""
+        o = self._new(OBJ_QUADRIC, clr, ks)
+        o["a"] = QUADRIC_KINDS[kind] if isinstance(kind, str) else tuple(int(v) for v in kind)
+        o["p"] = center
+        o["n0"] = n0; o["n1"] = n1; o["n2"] = n2
+        o["s"] = tuple(float(np.float32(v)) for v in s)
         self.objects.append(o)
         return len(self.objects) - 1
 

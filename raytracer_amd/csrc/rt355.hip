@@ -39,7 +39,7 @@
 #include "../../include/rt355.h"
 #include "rt_exact.h"
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 #define SEARCH_THREADS 256
 #ifndef RAYS_PER_THREAD
 #define RAYS_PER_THREAD 4   // rays per lane of the search kernel (2, 4 or 8)
@@ -84,6 +84,7 @@ __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, u
 #define CAND_SPHERE 0x40000000u
 #define CAND_TRI 0x80000000u
 #define CAND_ENVIRONMENT (CAND_SPHERE | CAND_TRI) // both bits: an Environment (its record is a sphere's)
+#define REC_QUADRIC (-2) // neither bit: a plane or a quadric, told apart by the second int of the record (-1 | -2)
 #define CAND_INDEX 0x3fffffffu
 #define CAND_UNSEARCHED 0xffffffffu // candidate count of a ray the search left to the fp64 walk over everything
 #ifndef CAND_BATCH
@@ -211,7 +212,7 @@ __device__ __forceinline__ TableRow bundle_origin_row(const SceneView &s, d3 O, 
         d3 ctr; double rad; bool sphere_like = false;
         if (tri < 0) {
             const DObject &o = s.objects[obj];
-            if (o.type == RT_OBJ_PLANE || o.type == RT_OBJ_ENVIRONMENT) { l1 = always; sin_t = 0.f; } // (an Environment surrounds the scene)
+            if (o.type == RT_OBJ_PLANE || o.type == RT_OBJ_ENVIRONMENT || o.type == RT_OBJ_QUADRIC) { l1 = always; sin_t = 0.f; } // (an Environment surrounds the scene; a quadric is unbounded)
             else { ctr = ld3(o.p); rad = fabs(o.radius); sphere_like = true; }
         } else {
             const DTriangle &t = s.tris[tri];
@@ -303,7 +304,7 @@ __device__ __forceinline__ TableRow bundle_direction_row(const SceneView &s, con
         d3 ctr; double rad = 0; bool round_like = false;
         if (tri < 0) {
             const DObject &o = s.objects[obj];
-            if (o.type == RT_OBJ_ENVIRONMENT) {
+            if (o.type == RT_OBJ_ENVIRONMENT || o.type == RT_OBJ_QUADRIC) {
                 l1 = always;
             } else if (o.type == RT_OBJ_PLANE) {
                 // Plane::CalcIntersect misses when ni . npe >= 0 (anyobject.h:80); npe = w up to rounding
@@ -1427,6 +1428,9 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
                         zero_obj = obj;
                         return;
                     }
+                } else if (ENV && __double2hiint(rec.x) == REC_QUADRIC) {
+                    int outside, branch;
+                    t = quadric_t(s.quadrics[s.objects[__double2loint(rec.x)].tri_begin], e, &outside, &branch);
                 } else {
                     t = plane_t(s.objects[__double2loint(rec.x)], e);
                 }
@@ -1508,6 +1512,9 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
                     int outside; d3 ph; double u, v;
                     t = tri_t(s.tris[__double2hiint(rec[j].x)], e, &outside, &ph, &u, &v);
                     if (t == 0) { general = true; t = -1; }
+                } else if (__double2hiint(rec[j].x) == REC_QUADRIC) {
+                    int outside, branch;
+                    t = quadric_t(s.quadrics[s.objects[__double2loint(rec[j].x)].tri_begin], e, &outside, &branch);
                 } else {
                     t = plane_t(s.objects[__double2loint(rec[j].x)], e);
                 }
@@ -1624,6 +1631,12 @@ __device__ __forceinline__ HitGeo hit_geometry(const SceneView &s, const Ray &e,
         environment_t_rec(make_double4(o.p[0], o.p[1], o.p[2], o.radius), e, &inside);
         h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // anyobject.h:215
         h.nh = vmul(normalize(vsub(ld3(o.p), h.ph)), (double)inside); // :218
+    } else if (ENV && o.type == RT_OBJ_QUADRIC) {
+        const DQuadric &q = s.quadrics[o.tri_begin];
+        int outside, branch;
+        quadric_t(q, e, &outside, &branch);
+        h.ph = vadd(e.pe, vmul(e.npe, c.t_best));                    // anyobject.h:314,328
+        h.nh = vmul(quadric_normal(q, h.ph), (double)outside);       // :320,339
     } else {
         int outside;
         sphere_t(o, e, &outside);
@@ -2247,6 +2260,11 @@ __global__ void k_probe_intersect(SceneView s, int obj, const double *__restrict
         int inside;
         t = environment_t_rec(make_double4(o.p[0], o.p[1], o.p[2], o.radius), e, &inside);
         if (t != -1) { ph = vadd(e.pe, vmul(e.npe, t)); nh = vmul(normalize(vsub(ld3(o.p), ph)), (double)inside); }
+    } else if (o.type == RT_OBJ_QUADRIC) {
+        const DQuadric &q = s.quadrics[o.tri_begin];
+        int outside, branch;
+        t = quadric_t(q, e, &outside, &branch);
+        if (branch) { ph = vadd(e.pe, vmul(e.npe, t)); nh = vmul(quadric_normal(q, ph), (double)outside); }
     } else {
         double t_min = RT_FLT_MAX; int best = -1;
         for (int q = 0; q < o.tri_count; q++) {
@@ -2525,21 +2543,22 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         return fail(RT355_ERR_ARG, "rt355_scene_create: inconsistent counts/pointers");
     std::vector<DObject> objs(d->n_objects);
     std::vector<DTriangle> tris(d->n_triangles);
-    std::vector<int32_t> prim_obj, prim_tri, by_kind[4]; // planes, spheres, triangles, environments
+    std::vector<int32_t> prim_obj, prim_tri, by_kind[5]; // planes, spheres, triangles, environments, quadrics
+    std::vector<DQuadric> quadrics;
     std::vector<double4> prim_rec;
     bool any_ks = false;
     double rmax = 0, extent = 0, ks_abs_max = 0;
     for (int i = 0; i < d->n_objects; i++) {
         const rt355_object &o = d->objects[i];
-        if (o.type != RT355_OBJ_PLANE && o.type != RT355_OBJ_SPHERE && o.type != RT355_OBJ_MESH && o.type != RT355_OBJ_ENVIRONMENT)
-            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": only Plane, Sphere, Environment and Mesh are accelerated");
+        if (o.type < RT355_OBJ_PLANE || o.type > RT355_OBJ_QUADRIC)
+            return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": type is one of RT355_OBJ_*");
         if (o.fresnel != 1)
             return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": fresnel != 1 (refraction, main.cpp:116-154, is not accelerated)");
         if (o.ks != 0) any_ks = true;
         ks_abs_max = std::max(ks_abs_max, std::isfinite(o.ks) ? fabs(o.ks) : 1e300);
         if (o.texture_type < 0 || o.texture_type > 3)
             return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": texture_type is 0, 1, 2 or 3 (anyobject.h:27-29)");
-        if ((o.texture_type == 1 || o.texture_type == 2) && (o.tex0 < 0 || o.tex1 < 0 || o.tex0 >= d->n_textures || o.tex1 >= d->n_textures))
+        if ((o.texture_type == 1 || o.texture_type == 2) && !(o.texture_type == 1 && o.type == RT355_OBJ_QUADRIC) && (o.tex0 < 0 || o.tex1 < 0 || o.tex0 >= d->n_textures || o.tex1 >= d->n_textures))
             return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": texture mapping needs textures[0] and textures[1]");
         if (o.texture_type == 3 && (o.tex0 < 0 || o.tex0 >= d->n_textures)) // shader.h:66 calls through textures[0]
             return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": texture_type 3 needs textures[0]");
@@ -2565,6 +2584,24 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
                 prim_obj.push_back(i); prim_tri.push_back(o.tri_begin + k);
                 prim_rec.push_back(index_rec(i, o.tri_begin + k));
             }
+        } else if (o.type == RT355_OBJ_QUADRIC) {
+            DQuadric k;
+            memcpy(k.pc, o.p, sizeof k.pc); memcpy(k.n0, o.n0, sizeof k.n0); memcpy(k.n1, o.n1, sizeof k.n1); memcpy(k.n2, o.n2, sizeof k.n2);
+            for (int a = 0; a < 5; a++) {
+                if (o.a[a] < -(1 << 30) || o.a[a] > (1 << 30)) // the formulas double them as ints (anyobject.h:304)
+                    return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": quadric coefficient out of range");
+                k.a[a] = (double)o.a[a];
+            }
+            for (int a = 0; a < 3; a++) {
+                k.s[a] = o.s[a];
+                k.c2[a] = (double)(2 * o.a[a]) / (o.s[a] * o.s[a]); // 2 * aCoor[i] / pow(sCoor[i], 2), :304,317,334
+            }
+            k.k = (double)o.a[3] / o.s[2];                           // aCoor[3] / sCoor[2], :285,300,301,315,331
+            q.tri_begin = (int32_t)quadrics.size(); q.tri_count = 0;
+            quadrics.push_back(k);
+            by_kind[4].push_back((int32_t)prim_obj.size());
+            prim_obj.push_back(i); prim_tri.push_back(-1);
+            prim_rec.push_back(index_rec(i, REC_QUADRIC));
         } else {
             by_kind[o.type == RT355_OBJ_SPHERE ? 1 : (o.type == RT355_OBJ_ENVIRONMENT ? 3 : 0)].push_back((int32_t)prim_obj.size());
             prim_obj.push_back(i); prim_tri.push_back(-1);
@@ -2604,13 +2641,14 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     std::vector<int32_t> kind_prims(by_kind[0]);
     kind_prims.insert(kind_prims.end(), by_kind[1].begin(), by_kind[1].end());
     kind_prims.insert(kind_prims.end(), by_kind[3].begin(), by_kind[3].end());
+    kind_prims.insert(kind_prims.end(), by_kind[4].begin(), by_kind[4].end());
     kind_prims.insert(kind_prims.end(), by_kind[2].begin(), by_kind[2].end());
     rt355_scene *sc = new rt355_scene();
     HIP_TRY(hipGetDevice(&sc->device));
     int rc;
     if ((rc = upload(sc, kind_prims, &sc->view.kind_prims)) || (rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
         (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
-        (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || 
+        (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || (rc = upload(sc, quadrics, &sc->view.quadrics)) ||
         (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels))) {
         rt355_scene_destroy(sc);
         return rc;
@@ -2618,7 +2656,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->view.n_objects = d->n_objects;
     sc->view.n_prims = (int)prim_obj.size();
     sc->view.n_planes = (int)by_kind[0].size(); sc->view.n_spheres = (int)by_kind[1].size();
-    sc->view.n_envs = (int)by_kind[3].size();
+    sc->view.n_envs = (int)by_kind[3].size(); sc->view.n_quadrics = (int)by_kind[4].size();
     sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
     if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
     if (const char *e = getenv("RT355_PACKET_RAYS")) {
@@ -3025,9 +3063,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
 #undef LAUNCH_GATHER
 #define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
         else if (sc->reflective) {
-            if (sc->view.n_envs > 0) LAUNCH_DIRECT(true, true); else LAUNCH_DIRECT(true, false);
+            if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(true, true); else LAUNCH_DIRECT(true, false);
         } else {
-            if (sc->view.n_envs > 0) LAUNCH_DIRECT(false, true); else LAUNCH_DIRECT(false, false);
+            if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(false, true); else LAUNCH_DIRECT(false, false);
         }
 #undef LAUNCH_DIRECT
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));

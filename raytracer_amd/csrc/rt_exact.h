@@ -17,6 +17,7 @@
 #define RT_OBJ_SPHERE 1
 #define RT_OBJ_MESH 2
 #define RT_OBJ_ENVIRONMENT 3
+#define RT_OBJ_QUADRIC 4
 
 struct d3 { double x, y, z; };
 
@@ -75,6 +76,13 @@ struct DObject { // one entry of Scene::objs, as uploaded
     uint32_t rgb; // 0x00BBGGRR
     int32_t pad_;
     double ks;    // reflection coefficient (anyobject.h:22)
+};
+struct DQuadric { // Quadric (anyobject.h:231-350): its members, and the constants its formulas divide out every call
+    double pc[3], n0[3], n1[3], n2[3]; // pCenter, nCoor[0..2]
+    double s[3];                       // sCoor
+    double a[5];                       // aCoor (ints, held as the doubles the formulas convert them to)
+    double k;                          // aCoor[3] / sCoor[2]
+    double c2[3];                      // 2 * aCoor[i] / pow(sCoor[i], 2)
 };
 struct DTriangle { // Triangle with its ctor-derived members (anyobject.h:456-461)
     double p0[3], p1[3], p2[3];
@@ -160,6 +168,44 @@ __device__ __forceinline__ double environment_t_rec(const double4 &q, const Ray 
     if (delta < 0) return -1;
     return B + sqrt(delta);
 }
+// Quadric::CalcIntersect, anyobject.h:283-345, as the path calls it (outside = 0 on entry).  pow(x, 2) is x * x
+// (exact either way).  *branch: 0 a miss (t = -1), 1 a hit from the A == 0 branch, 2 a hit from the quadratic
+// branch.  A hit returns whatever t the formula gives, negative ones too.
+__device__ __forceinline__ double quadric_t(const DQuadric &q, const Ray &e, int *outside_out, int *branch) {
+    const d3 d = vsub(e.pe, ld3(q.pc));
+    const double qd[3] = {dot(ld3(q.n0), d), dot(ld3(q.n1), d), dot(ld3(q.n2), d)};
+    const double rd[3] = {dot(ld3(q.n0), e.npe), dot(ld3(q.n1), e.npe), dot(ld3(q.n2), e.npe)};
+    double A = 0;
+    double B = q.k * rd[2];
+    double C = q.k * qd[2] + q.a[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double u = rd[i] / q.s[i], v = qd[i] / q.s[i];
+        A += q.a[i] * (u * u);
+        B += q.c2[i] * rd[i] * qd[i];
+        C += q.a[i] * (v * v);
+    }
+    *outside_out = (C < 0) ? -1 : 1; // Fp of :285-296 is C, term by term
+    *branch = 0;
+    if (A == 0) {
+        if (B != 0) { *branch = 1; return -(C / B); }
+        return -1.0;
+    }
+    const double delta = B * B - 4 * A * C;
+    if (delta >= 0) { *branch = 2; return (-B - sqrt(delta)) / (2 * A); }
+    return -1.0;
+}
+// The normal at ph, anyobject.h:315-319 / 331-337, before the factor `outside`.  In the A == 0 branch the
+// reference's loop over the three axes starts from an uninitialised index (`for (int i; ...`, :316): it is
+// taken to run from 0 like its twin at :333, which is also what g++ -O2 makes of it.
+__device__ __forceinline__ d3 quadric_normal(const DQuadric &q, d3 ph) {
+    d3 nh = vmul(ld3(q.n2), q.k);
+    const d3 d = vsub(ph, ld3(q.pc));
+    nh = vadd(nh, vmul(ld3(q.n0), q.c2[0] * dot(ld3(q.n0), d)));
+    nh = vadd(nh, vmul(ld3(q.n1), q.c2[1] * dot(ld3(q.n1), d)));
+    nh = vadd(nh, vmul(ld3(q.n2), q.c2[2] * dot(ld3(q.n2), d)));
+    return normalize(nh);
+}
 // Triangle::CalcIntersect, anyobject.h:475-522
 __device__ __forceinline__ double tri_t(const DTriangle &t, const Ray &e, int *outside_out, d3 *ph_out,
                                         double *u_out, double *v_out) {
@@ -222,8 +268,10 @@ struct SceneView { // device pointers of an uploaded scene
     const DTexture *textures;
     const uint8_t *texels;
     const int32_t *kind_prims; // the primitives sorted by kind: n_planes planes, n_spheres spheres, n_envs
-                               // environments, then the triangles of all meshes, each kind in scene-list order
-    int32_t n_objects, n_prims, n_planes, n_spheres, n_envs;
+                               // environments, n_quadrics quadrics, then the triangles of all meshes, each kind
+                               // in scene-list order
+    const DQuadric *quadrics;  // a quadric object's record is quadrics[object.tri_begin]
+    int32_t n_objects, n_prims, n_planes, n_spheres, n_envs, n_quadrics;
 };
 
 __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray &e, int *is_mesh, int *obj_out) {
@@ -239,6 +287,7 @@ __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray
     const DObject &o = s.objects[obj];
     if (o.type == RT_OBJ_PLANE) return plane_t(o, e);
     int outside;
+    if (o.type == RT_OBJ_QUADRIC) { int branch; return quadric_t(s.quadrics[o.tri_begin], e, &outside, &branch); }
     if (o.type == RT_OBJ_ENVIRONMENT) return environment_t_rec(make_double4(o.p[0], o.p[1], o.p[2], o.radius), e, &outside);
     return sphere_t(o, e, &outside);
 }
@@ -249,7 +298,7 @@ __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray
 // spheres are objects of their own; the triangles arrive in list order and go through Closest, which keeps
 // the mesh rules.  POSITIVE: hits need t > 0 (gather rays, shader.h:130,176), else t >= 0.  ANY: stop at
 // the first hit found, whichever it is (shading2 only asks whether there is one, shader.h:130-133).
-// ENV = false: the caller knows that the scene holds no Environment (its loop is compiled out).
+// ENV = false: the caller knows that the scene holds no Environment and no quadric (their loops are compiled out).
 template <bool POSITIVE, bool ANY, bool ENV = true>
 __device__ __forceinline__ void closest_by_kind(const SceneView &s, const Ray &e, double &t_best, int &prim_best) {
     double bt = RT_FLT_MAX;
@@ -269,12 +318,20 @@ __device__ __forceinline__ void closest_by_kind(const SceneView &s, const Ray &e
             consider(sphere_t_rec(s.prim_rec[prim], e), prim);
             if (ANY && bprim >= 0) break;
         }
-    const int first_tri = s.n_planes + s.n_spheres + (ENV ? s.n_envs : 0);
+    const int first_quadric = s.n_planes + s.n_spheres + (ENV ? s.n_envs : 0);
+    const int first_tri = first_quadric + (ENV ? s.n_quadrics : 0);
     if (ENV && !(ANY && bprim >= 0))
-        for (k = s.n_planes + s.n_spheres; k < first_tri; k++) {
+        for (k = s.n_planes + s.n_spheres; k < first_quadric; k++) {
             const int prim = s.kind_prims[k];
             int inside;
             consider(environment_t_rec(s.prim_rec[prim], e, &inside), prim);
+            if (ANY && bprim >= 0) break;
+        }
+    if (ENV && !(ANY && bprim >= 0))
+        for (k = first_quadric; k < first_tri; k++) {
+            const int prim = s.kind_prims[k];
+            int outside, branch;
+            consider(quadric_t(s.quadrics[s.objects[s.prim_obj[prim]].tri_begin], e, &outside, &branch), prim);
             if (ANY && bprim >= 0) break;
         }
     if (!(ANY && bprim >= 0) && first_tri < s.n_prims) {
@@ -326,6 +383,7 @@ __device__ __forceinline__ uint32_t tex_plane(const DTexture &t, const uint8_t *
 // Shader::TextureMapping, shader.h:196-288 (normal map off, shader.h:23)
 __device__ __forceinline__ void texture_mapping(const SceneView &s, const DObject &o, d3 ph, double uvx,
                                                 double uvy, uint32_t *cm0, uint32_t *cm1) {
+    if (o.type == RT_OBJ_QUADRIC) { *cm0 = 0u; *cm1 = 0u; return; } // no branch of shader.h:198-285 takes it: Color()
     const DTexture &t0 = s.textures[o.tex0];
     const DTexture &t1 = s.textures[o.tex1];
     if (o.type == RT_OBJ_SPHERE || o.type == RT_OBJ_ENVIRONMENT) { // shader.h:198

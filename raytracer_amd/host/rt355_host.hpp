@@ -109,6 +109,26 @@ public:
     const std::string GetObjectType() const override { return "Environment"; }
 };
 
+class Quadric : public AnyObject { // anyobject.h:231-350: sum of aCoor[i] * ((nCoor[i] . (p - pCenter)) / sCoor[i])^2 ...
+public:
+    Point3D pCenter; int aCoor[5] = {0, 0, 0, 1, 0}; // a02, a12, a22, a21, a00; the default is a plane (:242-249)
+    Vector3D nCoor[3]; double sCoor[3] = {0, 0, 0}; Color clr;
+    Quadric() {}
+    Quadric(int a0, int a1, int a2, int a3, int a4) { aCoor[0] = a0; aCoor[1] = a1; aCoor[2] = a2; aCoor[3] = a3; aCoor[4] = a4; }
+    void SetN(Vector3D n0, Vector3D n1, Vector3D n2) { nCoor[0] = n0; nCoor[1] = n1; nCoor[2] = n2; }
+    void SetS(float s0, float s1, float s2) { sCoor[0] = s0; sCoor[1] = s1; sCoor[2] = s2; } // floats, as :265
+    void SetPCenter(Point3D pc) { pCenter = pc; }
+    void SetColor(Color c) { clr = c; }
+    void SetKs(double k) { ks = k; }
+    const std::string GetObjectType() const override { return "Quadric"; }
+};
+// anyobject.h:355-442: the subclasses set aCoor and their name
+class Cone : public Quadric { public: Cone() : Quadric(1, 1, -1, 0, 0) {} const std::string GetObjectType() const override { return "Cone"; } };
+class Ellipsoid : public Quadric { public: Ellipsoid() : Quadric(1, 1, 1, 0, -1) {} const std::string GetObjectType() const override { return "Ellipsoid"; } };
+class Cylinder : public Quadric { public: Cylinder() : Quadric(1, 1, 0, 0, -1) {} const std::string GetObjectType() const override { return "Cylinder"; } };
+class EllipticParaboloid : public Quadric { public: EllipticParaboloid() : Quadric(1, 1, 0, -1, 0) {} const std::string GetObjectType() const override { return "EllipticParaboloid"; } };
+class HyperbolicParaboloid : public Quadric { public: HyperbolicParaboloid() : Quadric(1, -1, 0, -1, 0) {} const std::string GetObjectType() const override { return "HyperbolicParaboloid"; } };
+
 struct Triangle { // anyobject.h:444-532 (data members only)
     Point3D p0, p1, p2; Vector2D UV_p0, UV_p1, UV_p2; // (0, 0) until SetUV, as the reference's members are
     Triangle(Point3D a, Point3D b, Point3D c) : p0(a), p1(b), p2(c) {}
@@ -223,6 +243,11 @@ public:
                 q.type = dynamic_cast<const Environment *>(a) ? RT355_OBJ_ENVIRONMENT : RT355_OBJ_SPHERE;
                 detail::put(q.p, s->pCenter); q.radius = s->radius;
                 detail::put(q.n0, s->n0); detail::put(q.n1, s->n1); detail::put(q.n2, s->n2); detail::put(q.rgb, s->clr);
+            } else if (auto k = dynamic_cast<const Quadric *>(a)) {
+                q.type = RT355_OBJ_QUADRIC; detail::put(q.p, k->pCenter); detail::put(q.rgb, k->clr);
+                detail::put(q.n0, k->nCoor[0]); detail::put(q.n1, k->nCoor[1]); detail::put(q.n2, k->nCoor[2]);
+                for (int i = 0; i < 3; i++) q.s[i] = k->sCoor[i];
+                for (int i = 0; i < 5; i++) q.a[i] = k->aCoor[i];
             } else if (auto m = dynamic_cast<const Mesh *>(a)) {
                 q.type = RT355_OBJ_MESH; detail::put(q.rgb, m->clr);
                 q.tri_begin = (int32_t)t.size(); q.tri_count = (int32_t)m->triangles.size();

@@ -339,9 +339,34 @@ def small_case(name: str):
         s.set_texture_type(env, 3)
         del s.objects[0]   # the back wall: the sky behind the spheres
         return s, default_shader(2), default_camera(w, h), w, h
+    if name in ("quadrics", "quadrics_spheres"):
+        # one of each Quadric subclass (anyobject.h:355-442), the default Quadric (a plane) and a general one, on
+        # tilted axes; the unbounded ones cross each other and the floor.  "quadrics_spheres": the same among
+        # enough spheres for the searched modes, where a quadric is a candidate of every ray.
+        w, h = 160, 120
+        s = Scene()
+        s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230), ks=0.2)
+        ax = (_n((1, 0.1, 0)), _n((-0.1, 1, 0.2)), _n((0, -0.2, 1)))
+        s.add_quadric("Ellipsoid", (-12, 2, 0), *ax, (6, 4, 8), (200, 90, 90), ks=0.5)
+        s.add_quadric("Cylinder", (14, 8, 0), *ax, (3, 3, 1), (90, 200, 90))
+        s.add_quadric("Cone", (2, 10, 6), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 2.5), (90, 90, 220))
+        s.add_quadric("EllipticParaboloid", (-2, -2, -9), *ax, (2, 2, 0.4), (220, 200, 80), ks=0.3)
+        s.add_quadric("HyperbolicParaboloid", (20, 30, -5), (1, 0, 0), (0, 1, 0), (0, 0, 1), (4, 4, 0.5), (80, 200, 220))
+        s.add_quadric("Quadric", (0, 38, 0), (1, 0, 0), (0, 0, 1), (0, -1, 0), (1, 1, 2), (180, 180, 180))
+        s.add_quadric((2, -1, 1, 1, -3), (-22, 12, 4), *ax, (3, 5, 2), (160, 120, 200))
+        if name == "quadrics_spheres":
+            w, h = 128, 96
+            sp = spheres_scene(120, seed=83)
+            for i, o in enumerate(sp.objects):
+                if i % 5 == 1:
+                    o["ks"] = 0.6
+            s.objects.extend(sp.objects)
+            return s, Shader(ring_lights(3), 0x101010, 0xDDDDDD, 0x202020), default_camera(w, h), w, h
+        return s, default_shader(2), default_camera(w, h), w, h
     raise KeyError(name)
 
 
 SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
                "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside", "mirrors", "mirrors_mesh",
-               "environment", "environment_spheres", "solid_texture", "function_3d"]
+               "environment", "environment_spheres", "solid_texture", "function_3d",
+               "quadrics", "quadrics_spheres"]

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in rt355.h but not exported"
     L.rt355_abi_version.restype = ctypes.c_int
-    assert L.rt355_abi_version() >= 4
+    assert L.rt355_abi_version() >= 5
     # the exported jitter and its Python mirror
     from raytracer_amd import binding as B
     L.rt355_jitter.restype = ctypes.c_double
@@ -35,8 +35,21 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header_layout():
     from raytracer_amd import binding as B
-    assert B.OBJECT_DTYPE.itemsize == 184 and B.LIGHT_DTYPE.itemsize == 80
+    assert B.OBJECT_DTYPE.itemsize == 232 and B.LIGHT_DTYPE.itemsize == 80
     assert ctypes.sizeof(B.CCamera) == 96 and ctypes.sizeof(B.CStats) == 80
+    # ... and what the C compiler makes of the header itself
+    import subprocess, tempfile
+    prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "rt355.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+            'sizeof(rt355_object), offsetof(rt355_object, s), offsetof(rt355_object, a), sizeof(rt355_texture), '
+            'offsetof(rt355_texture, n0), sizeof(rt355_light), sizeof(rt355_opts), sizeof(rt355_stats)); return 0; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sizes.c")
+        open(src, "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "sizes"), src])
+        got = [int(v) for v in subprocess.check_output([os.path.join(d, "sizes")]).split()]
+    assert got == [B.OBJECT_DTYPE.itemsize, B.OBJECT_DTYPE.fields["s"][1], B.OBJECT_DTYPE.fields["a"][1],
+                   ctypes.sizeof(B.CTexture), B.CTexture.n0.offset, B.LIGHT_DTYPE.itemsize,
+                   ctypes.sizeof(B.COpts), ctypes.sizeof(B.CStats)]
 
 
 def test_null_arguments_are_rejected_without_a_gpu():

@@ -519,6 +519,45 @@ def test_random_scenes_inside_an_environment(api, oracle, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40, 48))
+def test_random_scenes_with_quadrics(api, oracle, seed):
+    """The random scenes with two to four random quadrics (anyobject.h:231-442: the five subclasses, the default
+    "plane" and general integer coefficients, axes neither unit nor orthogonal, float scales), some of them
+    mirrors: candidates of every ray in the searched modes, one loop of their own in the unsearched one.  All
+    three modes against the checker, the gather shaders on the odd seeds."""
+    sc, sh, cam, w, h = _random_case(seed)
+    rng = S.SplitMix64(5151 + seed)
+    kinds = list(B.QUADRIC_KINDS)
+    for _ in range(int(rng.uniform(2, 5))):
+        kind = kinds[int(rng.uniform(0, len(kinds)))] if rng.uniform() < 0.8 else tuple(int(rng.uniform(-2, 3)) for _ in range(5))
+        axes = [(1 + rng.uniform(-0.2, 0.2), rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3)),
+                (rng.uniform(-0.3, 0.3), 1 + rng.uniform(-0.2, 0.2), rng.uniform(-0.3, 0.3)),
+                (rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 1 + rng.uniform(-0.2, 0.2))]
+        sc.add_quadric(kind, (rng.uniform(-20, 20), rng.uniform(0, 30), rng.uniform(-8, 10)), *axes,
+                       (rng.uniform(1, 6), rng.uniform(1, 6), rng.uniform(0.3, 6)),
+                       (int(rng.uniform(30, 255)), int(rng.uniform(30, 255)), int(rng.uniform(30, 255))),
+                       ks=(0.0, 0.0, 0.5, 0.9)[int(rng.uniform(0, 4))])
+    if seed % 3 == 0:      # a quadric as object 0
+        sc.objects.insert(0, sc.objects.pop())
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    r = api.Renderer(sc)
+    for mode in (B.MODE_PACKET, B.MODE_ALLPAIRS, B.MODE_BRUTE):
+        got, st = r.render(cam, sh, w, h, mode=mode)
+        _compare(got, want)
+        assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"], mode
+    if seed % 2:
+        dirs = B.geodesic(B.icosphere(0))
+        r.set_directions(dirs)
+        shading = (B.SHADING_BLEED, B.SHADING_OCCLUSION)[(seed // 2) % 2]
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=2, seed=seed, shading=shading), threads=0, dirs=dirs)
+        for mode in (B.MODE_PACKET, B.MODE_BRUTE):
+            got, st = r.render(cam, sh, w, h, alias=2, seed=seed, shading=shading, mode=mode)
+            _compare(got, want)
+            assert st["gather_rays"] == wst["gather_rays"]
+    r.close()
+
+
+@pytest.mark.gpu
 def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
     """CalcSubPixel2 with shading3 / shading2 (main.cpp:163-209, shader.h:100-191), HEAD's renderer: frames
     the reference's own shader code produced (fixtures), then more cases against the CPU checker, ray counts
