@@ -2038,8 +2038,9 @@ __global__ __launch_bounds__(256) void k_gather_finish(SceneView s, ShaderView s
 }
 
 // LEVELS: the frame is rendered level by level (mirror rays on a searched scene); compiled apart so that frames
-// without levels run the kernel they always ran.
-template <bool LEVELS>
+// without levels run the kernel they always ran.  ENV: the scene holds an Environment or a quadric (their tests
+// are compiled out otherwise).
+template <bool LEVELS, bool ENV>
 __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f_in, Work w,
                                                          int brute, Group first,
                                                          unsigned char *__restrict__ pixmap) {
@@ -2067,20 +2068,20 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         e = grid_ray(cam, f, x, y);
     }
     Closest c;
-    closest_hit(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
+    closest_hit<false, ENV>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
         w.rec_obj[rid] = -1;
         if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
     n_hit = f.level > 0 ? 0 : 1; // rt355_stats.primary_hits counts camera rays
-    const bool environment = s.objects[s.prim_obj[c.prim_best]].type == RT_OBJ_ENVIRONMENT;
+    const bool environment = ENV && s.objects[s.prim_obj[c.prim_best]].type == RT_OBJ_ENVIRONMENT;
     if (sh.n_lights == 0 && f.level < 0 && !environment) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
         w.rec_obj[rid] = s.prim_obj[c.prim_best];
         store_pixel(pixmap, f, w, rid, x, y, 0u);
         break;
     }
-    const HitRec h = primary_record(s, sh, e, c);
+    const HitRec h = primary_record<ENV>(s, sh, e, c);
     if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, h.emissive ? h.cm0 : 0u); // (levels: the mirror ray still needs ph and nh)
     ph = h.ph; nh = h.nh;
     got_hit = !h.emissive; // an Environment is not lit: no shadow rays (shader.h:70-72)
@@ -3110,12 +3111,14 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         int rc1 = clear_bins(cur);
         if (rc1) return rc1;
         HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
-        if (levels)
-            hipLaunchKernelGGL(k_resolve_primary<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w,
-                               (L == 0 && !bundles[0].kind) ? 1 : 0, cur, pix);
-        else
-            hipLaunchKernelGGL(k_resolve_primary<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w,
-                               (L == 0 && !bundles[0].kind) ? 1 : 0, cur, pix);
+        {
+            const int brute_l = (L == 0 && !bundles[0].kind) ? 1 : 0;
+            const bool env = sc->view.n_envs + sc->view.n_quadrics > 0;
+#define LAUNCH_RESOLVE(LV, E) hipLaunchKernelGGL((k_resolve_primary<LV, E>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w, brute_l, cur, pix)
+            if (levels) { if (env) LAUNCH_RESOLVE(true, true); else LAUNCH_RESOLVE(true, false); }
+            else { if (env) LAUNCH_RESOLVE(false, true); else LAUNCH_RESOLVE(false, false); }
+#undef LAUNCH_RESOLVE
+        }
         HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
         resolves++;
         for (int j = 0; j < n_groups; j++) {
@@ -3152,7 +3155,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         Group none;
         memset(&none, 0, sizeof none);
         HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
-        hipLaunchKernelGGL(k_resolve_primary<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, no_lights, dc, fl, w,
+        hipLaunchKernelGGL((k_resolve_primary<true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, no_lights, dc, fl, w,
                            bundles[0].kind ? 0 : 1, none, pix);
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
         resolves = 1;
