@@ -41,7 +41,7 @@ def main():
     #     jitter taken from rt355_jitter in place of rand()
     meta["alias_cases"] = []
     for name, alias in (("default_2lights", 2), ("textured", 3), ("mesh", 2), ("spheres300_dir", 3),
-                        ("environment", 2), ("quadrics", 2)):
+                        ("environment", 2), ("quadrics", 2), ("glass", 2)):
         sc, sh, cam, w, h = S.small_case(name)
         w, h = w // 2, h // 2
         cam = S.default_camera(w, h)

@@ -215,45 +215,89 @@ View calc_view(const Cam &k, double x_per, double y_per) {
     return View(k.p_eye, npe);
 }
 
-// CalcSubPixel for outside = 1 and fresnel == 1 objects, re-expressed line by line with the reference's
-// classes: closest-hit loop and shading call (main.cpp:65-91), reflection recursion (main.cpp:93-112,
-// thresholds main.cpp:27-28).  The refraction branch (main.cpp:116-154) is not reached with fresnel == 1.
+// CalcSubPixel (main.cpp:42-158), re-expressed line by line with the reference's classes: the call on the
+// object the ray is inside of (:53-63), closest-hit loop and shading call (:65-91), reflection recursion
+// (:93-112, thresholds :27-28), refraction branches (:116-154).  The recursion has no bound of its own; `depth`
+// stops a chain that does not end before the stack does and reports it through g_too_deep.
+thread_local int g_too_deep = 0;
 Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd, int reflection_times = 0,
-                double reflection_ktotal = 1.0) {
+                double reflection_ktotal = 1.0, int outside = 1, int object_index = 0, int depth = 0) {
     double t_min = FLT_MAX;
-    int object_index = 0;
     Color clr = Color(0, 0, 0);
     Color cm0(0, 0, 0);
     Point3D ph(0, 0, 0);
     Vector3D nh(0, 0, 0);
     bool no_border = true;
     Vector2D UV(0, 0);
-    for (int i = 0; i < (int)objs.size(); i++) {
-        tuple<Color, double, Point3D, Vector3D, int> r = objs[i]->CalcIntersect(eye);
-        double t = get<1>(r);
-        if (t >= 0 && t < t_min) {
-            t_min = t; object_index = i;
-            cm0 = get<0>(r); ph = get<2>(r); nh = get<3>(r);
-            std::string kind = objs[i]->GetObjectType();
-            no_border = (kind == "Plane" || kind == "Mesh");
-            if (kind == "Mesh") UV = ((Mesh *)objs[i])->GetUV();
+    if (depth > 2000) { g_too_deep = 1; return clr; }
+    if (objs.empty()) return clr;
+    if (outside <= -1 && object_index >= 0) {
+        tuple<Color, double, Point3D, Vector3D, int> r = objs[object_index]->CalcIntersect(eye, outside);
+        t_min = get<1>(r); cm0 = get<0>(r); ph = get<2>(r); nh = get<3>(r);
+        std::string kind = objs[object_index]->GetObjectType();
+        no_border = (kind == "Plane" || kind == "Mesh");
+        if (kind == "Mesh") UV = ((Mesh *)objs[object_index])->GetUV();
+    } else {
+        for (int i = 0; i < (int)objs.size(); i++) {
+            tuple<Color, double, Point3D, Vector3D, int> r = objs[i]->CalcIntersect(eye);
+            double t = get<1>(r);
+            if (t >= 0 && t < t_min) {
+                t_min = t; object_index = i;
+                cm0 = get<0>(r); ph = get<2>(r); nh = get<3>(r);
+                std::string kind = objs[i]->GetObjectType();
+                no_border = (kind == "Plane" || kind == "Mesh");
+                if (kind == "Mesh") UV = ((Mesh *)objs[i])->GetUV();
+            }
         }
     }
     if (t_min != FLT_MAX)
         clr = shd.shading(cm0, shd.ambient_color, ph, nh, eye, no_border, objs, object_index, UV, 0, 0);
-    if (objs.empty()) return clr;
     double ks = objs[object_index]->ks;
     reflection_ktotal *= ks;
-    reflection_times++;
+    if (outside >= 1) reflection_times++;
     Color clr_reflection;
-    if (reflection_times <= 3 && reflection_ktotal >= 0.05) {
+    Color clr_refraction;
+    if (outside >= 1 && reflection_times <= 3 && reflection_ktotal >= 0.05) {
         Vector3D reflect_npe = eye.npe - nh * 2 * DotProduct(nh, eye.npe);
         View reflect_view = View(ph, reflect_npe);
-        clr_reflection = clr * (1 - ks) + sub_pixel(reflect_view, objs, shd, reflection_times, reflection_ktotal) * ks;
+        clr_reflection = clr * (1 - ks) + sub_pixel(reflect_view, objs, shd, reflection_times, reflection_ktotal, 1, 0, depth + 1) * ks;
     } else {
         clr_reflection = clr;
     }
-    return clr_reflection;
+    double fresnel = objs[object_index]->fresnel;
+    if (fresnel < 1) {
+        if (outside >= 1) {
+            Vector3D V = eye.npe * (-1);
+            double c = DotProduct(nh, V);
+            double IOR = 1 / objs[object_index]->IOR;
+            Vector3D T = V * (-IOR) + nh * (IOR * c - sqrt(pow(IOR * c, 2) - IOR * IOR + 1));
+            T = T.normalize();
+            View refract_view = View(ph, T);
+            clr_refraction = sub_pixel(refract_view, objs, shd, reflection_times, reflection_ktotal, -1, object_index, depth + 1);
+            clr = clr_reflection * fresnel + clr_refraction * (1 - fresnel);
+        } else {
+            Vector3D V = eye.npe * (-1);
+            double c = DotProduct(nh, V);
+            double IOR = objs[object_index]->IOR;
+            double delta = (pow(IOR * c, 2) - IOR * IOR + 1);
+            if (delta > 0) {
+                Vector3D T = V * (-IOR) + nh * (IOR * c - sqrt(delta));
+                T = T.normalize();
+                View refract_view = View(ph, T);
+                clr_refraction = sub_pixel(refract_view, objs, shd, reflection_times, reflection_ktotal, 1, object_index, depth + 1);
+            } else {
+                Vector3D reflect_npe;
+                reflect_npe = eye.npe - nh * 2 * DotProduct(nh, eye.npe);
+                View reflect_view = View(ph, reflect_npe);
+                if (outside-- <= -5) outside = 1;
+                clr_refraction = sub_pixel(reflect_view, objs, shd, reflection_times, reflection_ktotal, outside, object_index, depth + 1);
+            }
+            clr = clr_refraction;
+        }
+    } else {
+        clr = clr_reflection;
+    }
+    return clr;
 }
 
 // CalcSubPixel2 as CalcPixel calls it (main.cpp:163-209 with outside = 1), re-expressed; the shader call is the
@@ -342,6 +386,7 @@ int ref_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const 
             pixmap[i] = c.r; pixmap[i + 1] = c.g; pixmap[i + 2] = c.b;
         }
     for (light_src *l : ls) delete l;
+    if (g_too_deep) { g_too_deep = 0; return -2; } // a refraction chain that did not end
     return 0;
 }
 

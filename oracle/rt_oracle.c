@@ -159,7 +159,7 @@ static hit environment_isect(const rt355_object *o, ray e) {
  * (the divisions and powers repeated per call); pow(x, 2) is x * x.  In the A == 0 branch the reference's loop
  * over the axes starts from an uninitialised index (`for (int i; ...`, :316): it is taken to run from 0 like its
  * twin at :333, which is what the harness build (g++ -O2) does too. */
-static hit quadric_isect(const rt355_object *o, ray e) {
+static hit quadric_isect_k(const rt355_object *o, ray e, int outside_in) {
     hit h; memset(&h, 0, sizeof h);
     v3 pc = from3(o->p);
     v3 n[3] = {from3(o->n0), from3(o->n1), from3(o->n2)};
@@ -167,7 +167,7 @@ static hit quadric_isect(const rt355_object *o, ray e) {
     const double *s = o->s;
     double Fp = a[3] / s[2] * dot(n[2], vsub(e.pe, pc)) + a[4];
     for (int i = 0; i < 3; i++) { double v = dot(n[i], vsub(e.pe, pc)) / s[i]; Fp += a[i] * (v * v); }
-    int outside = (Fp < 0) ? -1 : 1;
+    int outside = outside_in ? outside_in : ((Fp < 0) ? -1 : 1); /* :289-296 */
     double A = 0;
     double B = a[3] / s[2] * dot(n[2], e.npe);
     double C = a[3] / s[2] * dot(n[2], vsub(e.pe, pc)) + a[4];
@@ -202,6 +202,8 @@ static hit quadric_isect(const rt355_object *o, ray e) {
     h.t = -1;
     return h;
 }
+
+static hit quadric_isect(const rt355_object *o, ray e) { return quadric_isect_k(o, e, 0); }
 
 /* Triangle::CalcIntersect, anyobject.h:475-522; u,v returned for GetUV (:524-526) */
 static hit tri_isect(const otri *t, ray e, double *u_out, double *v_out) {
@@ -246,6 +248,91 @@ static hit mesh_isect(const oscene *s, const rt355_object *o, ray e) {
     memset(&best, 0, sizeof best);
     best.t = -1;
     return best;
+}
+
+/* CalcIntersect(eye, outside) with outside != 0, as the refraction branches pass it (main.cpp:55 with the
+ * -1 .. -5 of :126,144-148).  Plane and Quadric use the value as given (anyobject.h:86,320,339), Sphere and
+ * Triangle its sign (:144,486), Environment takes it for its `inside` (:199-205).  A miss returns the tuple
+ * of the class's miss branch: t = -1, the point (0,0,0) and whatever normal that branch builds. */
+static hit plane_isect_k(const rt355_object *o, ray e, int outside) {
+    hit h; memset(&h, 0, sizeof h);
+    v3 ni = from3(o->n), pi = from3(o->p);
+    if (dot(ni, e.npe) >= 0) { h.t = -1; h.nh = vmul(normalize(ni), outside); return h; } /* :80-82 */
+    h.t = -dot(ni, vsub(e.pe, pi)) / dot(ni, e.npe);
+    h.ph = vadd(e.pe, vmul(e.npe, h.t));
+    h.nh = vmul(ni, outside);
+    return h;
+}
+static hit sphere_isect_k(const rt355_object *o, ray e, int outside) {
+    hit h; memset(&h, 0, sizeof h);
+    v3 c = from3(o->p);
+    double r = o->radius;
+    v3 ec = vsub(e.pe, c);
+    outside = (outside > 0) ? 1 : -1;
+    double B = dot(e.npe, vsub(c, e.pe));
+    double Cc = dot(ec, ec) - r * r;
+    double delta = B * B - Cc;
+    if (delta < 0) { h.t = -1; h.nh = vmul(V(0, 0, 0), outside); return h; }
+    h.t = B - outside * sqrt(delta);
+    h.ph = vadd(e.pe, vmul(e.npe, h.t));
+    h.nh = vmul(normalize(vsub(h.ph, c)), outside);
+    return h;
+}
+static hit environment_isect_k(const rt355_object *o, ray e, int inside) {
+    hit h; memset(&h, 0, sizeof h);
+    v3 c = from3(o->p);
+    double r = o->radius;
+    v3 ec = vsub(e.pe, c);
+    if (dot(ec, ec) - r * r >= 0.00001) inside = -1;
+    double B = dot(e.npe, vsub(c, e.pe));
+    double Cc = dot(ec, ec) - r * r;
+    double delta = B * B - Cc;
+    if (delta < 0) { h.t = -1; h.nh = vmul(V(0, 0, 0), inside); return h; }
+    h.t = B + sqrt(delta);
+    h.ph = vadd(e.pe, vmul(e.npe, h.t));
+    h.nh = vmul(normalize(vsub(c, h.ph)), inside);
+    return h;
+}
+static hit tri_isect_k(const otri *t, ray e, int outside, double *u_out, double *v_out) {
+    hit h; memset(&h, 0, sizeof h);
+    outside = (outside > 0) ? 1 : -1;
+    h.t = -1;
+    h.nh = vmul(normalize(t->normal), outside); /* the three miss branches, :491,500,520 */
+    if (dot(t->normal, e.npe) >= 0) return h;
+    double tt = -dot(t->normal, vsub(e.pe, t->p_center)) / dot(t->normal, e.npe);
+    if ((outside < 0 && tt > 0) || (tt < 0)) return h;
+    v3 ph = vadd(e.pe, vmul(e.npe, tt));
+    v3 AA = cross(vsub(t->p1, t->p0), vsub(t->p2, t->p0));
+    v3 A1 = cross(vsub(t->p2, ph), vsub(t->p0, ph));
+    v3 A2 = cross(vsub(t->p0, ph), vsub(t->p1, ph));
+    double u = (AA.x != 0) ? A1.x / AA.x : ((AA.y != 0) ? A1.y / AA.y : A1.z / AA.z);
+    double v = (AA.x != 0) ? A2.x / AA.x : ((AA.y != 0) ? A2.y / AA.y : A2.z / AA.z);
+    if (u >= 0 && v >= 0 && (u + v) <= 1) {
+        h.t = tt; h.ph = ph; h.nh = vmul(t->normal, outside);
+        *u_out = u; *v_out = v;
+    }
+    return h;
+}
+static hit mesh_isect_k(const oscene *s, const rt355_object *o, ray e, int outside) { /* anyobject.h:646-666 */
+    double t_min = FLT_MAX;
+    hit best; memset(&best, 0, sizeof best);
+    for (int i = 0; i < o->tri_count; i++) {
+        double u = 0, v = 0;
+        hit h = tri_isect_k(&s->tris[o->tri_begin + i], e, outside, &u, &v);
+        if (h.t >= 0 && h.t < t_min) { t_min = h.t; best = h; }
+    }
+    if (t_min > 0 && t_min != FLT_MAX) return best;
+    memset(&best, 0, sizeof best); /* Normalize(Vector3D(0,0,0)) is (0,0,0), :664 */
+    best.t = -1;
+    return best;
+}
+static hit obj_isect_k(const oscene *s, int i, ray e, int k) {
+    const rt355_object *o = &s->d->objects[i];
+    if (o->type == RT355_OBJ_PLANE) return plane_isect_k(o, e, k);
+    if (o->type == RT355_OBJ_SPHERE) return sphere_isect_k(o, e, k);
+    if (o->type == RT355_OBJ_ENVIRONMENT) return environment_isect_k(o, e, k);
+    if (o->type == RT355_OBJ_QUADRIC) return quadric_isect_k(o, e, k);
+    return mesh_isect_k(s, o, e, k);
 }
 
 static hit obj_isect(const oscene *s, int i, ray e) {
@@ -362,6 +449,7 @@ typedef struct {
     const double *dirs; /* geo, main.cpp:557 */
     int n_dirs;
     uint64_t gather_rays;
+    int too_deep; /* a refraction chain that does not end (see calc_subpixel_rec) */
 } octx;
 
 static col calc_diffuse(const rt355_light *L, col cm0, col cm1, v3 nh, v3 nhl) { /* shader.h:324-338 */
@@ -432,44 +520,80 @@ static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_bor
     return clr_sum;
 }
 
-/* CalcSubPixel, main.cpp:42-158, for outside = 1 and objects with fresnel == 1: closest hit and shading
- * (:65-91), then the reflection recursion (:93-112) with REFLECTION_TIMES_THRES 3 and
- * REFLECTION_KTOTAL_THRES 0.05 (:27-28).  On a miss object_index stays 0, ph and nh stay zero, and the
- * reference goes on with objs[0]'s ks (:94); so does this.  Refraction (:116-154) needs fresnel < 1. */
-static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double reflection_ktotal) {
+/* CalcSubPixel, main.cpp:42-158: closest hit and shading (:65-91), the reflection recursion (:93-112) with
+ * REFLECTION_TIMES_THRES 3 and REFLECTION_KTOTAL_THRES 0.05 (:27-28), the refraction branches (:116-154).  On a
+ * miss object_index keeps the value passed in (0 for camera and mirror rays), ph and nh stay zero, and the
+ * reference goes on with that object's ks and fresnel (:94,116); so does this.
+ * A call with outside <= -1 (a ray inside objs[object_index]) intersects that object alone, with `outside` as
+ * given (:53-63); its shading (:88) is evaluated by the reference and then overwritten (:150), so it is left
+ * out here, and with it its shadow rays.  Nothing bounds the refraction recursion (the thresholds of :103
+ * guard the mirror ray only): a chain that does not end -- a glass object 0 in an open scene -- overflows the
+ * reference's stack; here it sets too_deep. */
+#define ORACLE_MAX_DEPTH 2000
+static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double reflection_ktotal, int outside,
+                             int object_index, int depth) {
     int n = cx->s->d->n_objects;
     double t_min = FLT_MAX;
     hit best; memset(&best, 0, sizeof best);
-    int idx = 0, no_border = 1;
+    int idx = object_index, no_border = 1;
     col clr = C(0, 0, 0);
-    for (int i = 0; i < n; i++) {
-        hit h = obj_isect(cx->s, i, eye);
-        if (h.t >= 0 && h.t < t_min) {
-            t_min = h.t; idx = i; best = h;
-            no_border = (cx->s->d->objects[i].type == RT355_OBJ_PLANE || cx->s->d->objects[i].type == RT355_OBJ_MESH);
+    if (depth > ORACLE_MAX_DEPTH) { cx->too_deep = 1; return clr; }
+    if (outside <= -1 && object_index >= 0 && n > 0) {                         /* :53-63 */
+        best = obj_isect_k(cx->s, object_index, eye, outside);
+        t_min = best.t;
+    } else {
+        for (int i = 0; i < n; i++) {
+            hit h = obj_isect(cx->s, i, eye);
+            if (h.t >= 0 && h.t < t_min) {
+                t_min = h.t; idx = i; best = h;
+                no_border = (cx->s->d->objects[i].type == RT355_OBJ_PLANE || cx->s->d->objects[i].type == RT355_OBJ_MESH);
+            }
+        }
+        if (t_min != FLT_MAX) {
+            const rt355_object *o = &cx->s->d->objects[idx];
+            const rt355_shader *sh = cx->sh;
+            clr = shading(cx, C(o->rgb[0], o->rgb[1], o->rgb[2]),
+                          C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), best.ph, best.nh, eye,
+                          no_border, idx, best.uvx, best.uvy);
         }
     }
-    if (t_min != FLT_MAX) {
-        const rt355_object *o = &cx->s->d->objects[idx];
-        const rt355_shader *sh = cx->sh;
-        clr = shading(cx, C(o->rgb[0], o->rgb[1], o->rgb[2]),
-                      C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), best.ph, best.nh, eye,
-                      no_border, idx, best.uvx, best.uvy);
-    }
     if (n == 0) return clr; /* the reference would read objs[0] of an empty vector here */
-    double ks = cx->s->d->objects[idx].ks;                                     /* :94 */
+    const rt355_object *o = &cx->s->d->objects[idx];
+    double ks = o->ks;                                                         /* :94 */
     reflection_ktotal *= ks;                                                   /* :97 */
-    reflection_times++;                                                        /* :98-100, outside >= 1 */
-    if (reflection_times <= 3 && reflection_ktotal >= 0.05) {                  /* :103 */
+    if (outside >= 1) reflection_times++;                                      /* :98-100 */
+    col clr_reflection = clr;
+    if (outside >= 1 && reflection_times <= 3 && reflection_ktotal >= 0.05) {  /* :103 */
         v3 reflect_npe = vsub(eye.npe, vmul(vmul(best.nh, 2), dot(best.nh, eye.npe))); /* :104 */
         ray reflect_view = mkview(best.ph, reflect_npe);                      /* :108 */
         cx->secondary_rays++;
-        col sub = calc_subpixel_rec(cx, reflect_view, reflection_times, reflection_ktotal);
-        return cadd(cmul(clr, 1 - ks), cmul(sub, ks));                         /* :109 */
+        col sub = calc_subpixel_rec(cx, reflect_view, reflection_times, reflection_ktotal, 1, 0, depth + 1);
+        clr_reflection = cadd(cmul(clr, 1 - ks), cmul(sub, ks));               /* :109 */
     }
-    return clr;                                                                /* :111, :151 */
+    double fresnel = o->fresnel;                                               /* :116 */
+    if (!(fresnel < 1)) return clr_reflection;                                 /* :153 */
+    v3 Vv = vmul(eye.npe, -1);                                                 /* :119,129 */
+    double c = dot(best.nh, Vv);
+    if (outside >= 1) {
+        double IOR = 1 / o->ior;                                               /* :121 */
+        v3 T = vadd(vmul(Vv, -IOR), vmul(best.nh, IOR * c - sqrt((IOR * c) * (IOR * c) - IOR * IOR + 1))); /* :123 */
+        T = normalize(T);                                                      /* :124 */
+        cx->secondary_rays++;
+        col clr_refraction = calc_subpixel_rec(cx, mkview(best.ph, T), reflection_times, reflection_ktotal, -1, idx, depth + 1);
+        return cadd(cmul(clr_reflection, fresnel), cmul(clr_refraction, 1 - fresnel)); /* :127 */
+    }
+    double IOR = o->ior;                                                       /* :131 */
+    double delta = (IOR * c) * (IOR * c) - IOR * IOR + 1;                      /* :133 */
+    cx->secondary_rays++;
+    if (delta > 0) {
+        v3 T = normalize(vadd(vmul(Vv, -IOR), vmul(best.nh, IOR * c - sqrt(delta)))); /* :135-136 */
+        return calc_subpixel_rec(cx, mkview(best.ph, T), reflection_times, reflection_ktotal, 1, idx, depth + 1); /* :138,150 */
+    }
+    v3 reflect_npe = vsub(eye.npe, vmul(vmul(best.nh, 2), dot(best.nh, eye.npe))); /* :142 */
+    if (outside-- <= -5) outside = 1;                                          /* :144-146 */
+    return calc_subpixel_rec(cx, mkview(best.ph, reflect_npe), reflection_times, reflection_ktotal, outside, idx, depth + 1); /* :148,150 */
 }
-static col calc_subpixel(octx *cx, ray eye) { return calc_subpixel_rec(cx, eye, 0, 1.0); }
+static col calc_subpixel(octx *cx, ray eye) { return calc_subpixel_rec(cx, eye, 0, 1.0, 1, 0, 0); }
 
 /* sin and cos of the gather rotation, correctly rounded (evaluated in binary128 by libquadmath, rounded
  * once).  The reference calls its C library's sin and cos; those differ between libraries in the last bit
@@ -610,7 +734,7 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
     int y0 = opts->row_begin, y1 = opts->row_end;
     if (y0 == 0 && y1 == 0) y1 = H;
     if (stride < 1) stride = 1;
-    uint64_t prim = 0, shad = 0, sec = 0, gat = 0;
+    uint64_t prim = 0, shad = 0, sec = 0, gat = 0, deep = 0;
     const int shading = opts->shading;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -618,11 +742,11 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
     (void)n_threads;
     const int y_first = (y0 + stride - 1) / stride * stride; /* sampled rows: multiples of stride; dealt out one by one */
     const int n_sampled = y_first < y1 ? (y1 - y_first + stride - 1) / stride : 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : prim, shad, sec, gat)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : prim, shad, sec, gat, deep)
     for (int j = 0; j < n_sampled; j++) {
         const int y = y_first + j * stride;
         octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0; cx.secondary_rays = 0;
-        cx.dirs = dirs; cx.n_dirs = n_dirs; cx.gather_rays = 0;
+        cx.dirs = dirs; cx.n_dirs = n_dirs; cx.gather_rays = 0; cx.too_deep = 0;
         const int alias = opts->alias;
         for (int x = 0; x < W; x += stride) {
             col clr;
@@ -651,6 +775,7 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
         shad += cx.shadow_rays;
         sec += cx.secondary_rays;
         gat += cx.gather_rays;
+        deep += cx.too_deep;
     }
     free(s.tris);
     if (stats) {
@@ -660,6 +785,7 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
         stats->secondary_rays = sec;
         stats->gather_rays = gat;
     }
+    if (deep) return RT355_ERR_UNSUPPORTED;
     return RT355_OK;
 }
 

@@ -1770,6 +1770,215 @@ __global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView s
     if (REFLECT) wave_count(w.counters, 6, n_secondary);
 }
 
+// ---- refraction -----------------------------------------------------------------------------------------
+// CalcSubPixel with objects of fresnel < 1 (main.cpp:116-154).  A call with outside >= 1 shades its closest hit,
+// then casts the mirror ray while the thresholds of main.cpp:103 hold and -- whatever they say -- the
+// refracted ray INTO the object hit if that has fresnel < 1; its colour is
+//     (clr * (1 - ks) + mirror * ks) * fresnel + refracted * (1 - fresnel)            main.cpp:109,127
+// with 8-bit truncation after every product, so the terms cannot be reordered.  A call with outside <= -1
+// intersects only the object it is inside of, with `outside` as given (main.cpp:55), and returns what its one
+// child returns (main.cpp:150: the shading it evaluates at :88 is overwritten, so it is skipped here, shadow
+// rays included): the refracted ray out when (IOR c)^2 - IOR^2 + 1 > 0, else the mirrored ray inside with
+// outside counted down, and after -5 a call with outside = 1 from where the ray is (main.cpp:144-148).
+// The recursion is run as a loop: a node that waits for a child leaves (its colour so far, its object, what
+// to do with the child's colour) on a stack of REFRACT_OPS entries; a node with both children also leaves
+// what its second child starts from (at most 3 such nodes wait at a time: each raises reflection_times).
+// Nothing in the reference bounds the refracted chain -- a ray that leaves a glass object and hits nothing goes
+// on from the origin with that object's coefficients for ever (main.cpp:94,116) and overflows its stack --
+// so a pixel that fills the stack raises counter 14 and the frame is reported as failed.
+#define REFRACT_OPS 64
+#define REFRACT_SPAWNS 4
+#define OP_MIRROR 0u  // value = clr * (1 - ks) + child * ks
+#define OP_REFRACT 1u // value = clr * fresnel + child * (1 - fresnel)
+#define OP_BOTH 2u    // the mirror child first, then the refracted one
+struct RefractSpawn { d3 ph, nh, npe; double ktotal; int times, obj; };
+// objs[obj]->CalcIntersect(eye, k) for k <= -1: point and normal of the tuple returned (t is not used by the caller)
+__device__ __forceinline__ void intersect_inside(const SceneView &s, int obj, const Ray &e, int k, d3 *ph_out, d3 *nh_out) {
+    const DObject &o = s.objects[obj];
+    d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
+    if (o.type == RT_OBJ_PLANE) {                                    // anyobject.h:69-87, `outside` as given
+        const d3 ni = ld3(o.n);
+        if (dot(ni, e.npe) >= 0) {
+            nh = vmul(normalize(ni), (double)k);                     // :81
+        } else {
+            const double t = -dot(ni, vsub(e.pe, ld3(o.p))) / dot(ni, e.npe);
+            ph = vadd(e.pe, vmul(e.npe, t));
+            nh = vmul(ni, (double)k);                                // :86
+        }
+    } else if (o.type == RT_OBJ_SPHERE) {                            // :128-158, outside = -1 (:144)
+        const d3 c = ld3(o.p);
+        const d3 ec = vsub(e.pe, c);
+        const double B = dot(e.npe, vsub(c, e.pe));
+        const double Cc = dot(ec, ec) - o.radius * o.radius;
+        const double delta = B * B - Cc;
+        if (delta < 0) {
+            nh = vmul(D3(0, 0, 0), -1.0);                            // :151
+        } else {
+            const double t = B - (-1.0) * sqrt(delta);
+            ph = vadd(e.pe, vmul(e.npe, t));
+            nh = vmul(normalize(vsub(ph, c)), -1.0);
+        }
+    } else if (o.type == RT_OBJ_ENVIRONMENT) {                       // :199-220, inside = k unless the origin is outside
+        const d3 c = ld3(o.p);
+        const d3 ec = vsub(e.pe, c);
+        int inside = k;
+        if (dot(ec, ec) - o.radius * o.radius >= 0.00001) inside = -1;
+        const double B = dot(e.npe, vsub(c, e.pe));
+        const double Cc = dot(ec, ec) - o.radius * o.radius;
+        const double delta = B * B - Cc;
+        if (delta < 0) {
+            nh = vmul(D3(0, 0, 0), (double)inside);
+        } else {
+            const double t = B + sqrt(delta);
+            ph = vadd(e.pe, vmul(e.npe, t));
+            nh = vmul(normalize(vsub(c, ph)), (double)inside);
+        }
+    } else if (o.type == RT_OBJ_QUADRIC) {                           // :283-345, `outside` as given
+        const DQuadric &q = s.quadrics[o.tri_begin];
+        int outside, branch;
+        const double t = quadric_t(q, e, &outside, &branch);
+        if (branch) {
+            ph = vadd(e.pe, vmul(e.npe, t));
+            nh = vmul(quadric_normal(q, ph), (double)k);
+        }
+    }
+    // a Mesh: with outside < 0 a triangle reports a hit only at t == 0 exactly (anyobject.h:499), which the
+    // mesh then drops (t_min > 0, :659): always the miss tuple, point and normal zero (:664)
+    *ph_out = ph; *nh_out = nh;
+}
+__global__ __launch_bounds__(256) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+                                                        unsigned char *__restrict__ pixmap) {
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0, n_deep = 0;
+    do {
+    if (rid >= f.n_rays) break;
+    int x, y;
+    rid_to_xy(rid, f.tiles_x, &x, &y);
+    if (!(x < f.grid_w && y < f.grid_h)) break;
+    Ray e = grid_ray(cam, f, x, y);
+    Spill none; none.pool = nullptr; none.count = nullptr;
+    uint32_t op_clr[REFRACT_OPS], op_what[REFRACT_OPS]; // what = object | kind << 30
+    RefractSpawn spawn[REFRACT_SPAWNS];
+    int n_ops = 0, n_spawn = 0;
+    int times = 0, outside = 1, oi = 0;
+    double ktotal = 1.0;
+    uint32_t value = 0u;
+    bool first = true;
+    for (;;) {
+        // ---- one call of CalcSubPixel, down to its first child
+        d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
+        uint32_t own = 0u;
+        if (s.n_objects == 0) { value = 0u; break; } // (the reference would read objs[0] of an empty vector)
+        if (outside <= -1) {
+            intersect_inside(s, oi, e, outside, &ph, &nh);
+        } else {
+            Closest c;
+            closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
+            if (c.prim_best >= 0) {
+                if (first) n_hit = 1;
+                const HitRec h = primary_record(s, sh, e, c);
+                ph = h.ph; nh = h.nh; oi = h.obj;
+                if (h.emissive) own = h.cm0;
+                for (int k = 0; !h.emissive && k < sh.n_lights; k++)
+                    own = shade_light(sh, k, h, own, [&](const Ray &sr) {
+                        Closest o;
+                        closest_hit(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
+                        return o.t_best;
+                    }, n_shadow);
+            }
+        }
+        first = false;
+        const DObject &o = s.objects[oi];
+        const double ks = o.ks, fresnel = o.fresnel;                               // main.cpp:94,116
+        ktotal *= ks;                                                              // :97
+        bool to_child = false;
+        if (outside >= 1) {
+            times += 1;                                                            // :98-100
+            const bool mirror = times <= 3 && ktotal >= 0.05;                      // :103
+            const bool glass = fresnel < 1;                                        // :117
+            if (mirror || glass) {
+                if (n_ops == REFRACT_OPS || (mirror && glass && n_spawn == REFRACT_SPAWNS)) { n_deep = 1; value = 0u; n_ops = 0; break; }
+                op_clr[n_ops] = own;
+                op_what[n_ops] = (uint32_t)oi | ((mirror && glass) ? OP_BOTH : (mirror ? OP_MIRROR : OP_REFRACT)) << 30;
+                n_ops += 1;
+                n_secondary += 1;
+                if (mirror) {
+                    if (glass) {
+                        RefractSpawn &sp = spawn[n_spawn++];
+                        sp.ph = ph; sp.nh = nh; sp.npe = e.npe; sp.ktotal = ktotal; sp.times = times; sp.obj = oi;
+                    }
+                    e = mkview(ph, vsub(e.npe, vmul(vmul(nh, 2), dot(nh, e.npe)))); // :104-108
+                    outside = 1; oi = 0;                                           // :109: object_index defaults to 0
+                } else {
+                    const d3 V = vmul(e.npe, -1);                                  // :119-126
+                    const double c = dot(nh, V);
+                    const double IOR = 1 / o.ior;
+                    d3 T = vadd(vmul(V, -IOR), vmul(nh, IOR * c - sqrt((IOR * c) * (IOR * c) - IOR * IOR + 1)));
+                    e = mkview(ph, normalize(T));
+                    outside = -1;
+                }
+                to_child = true;
+            } else {
+                value = own;                                                       // :111,153
+            }
+        } else {
+            if (!(fresnel < 1)) { n_deep = 1; value = 0u; n_ops = 0; break; }      // (a ray is only ever inside a glass object)
+            const d3 V = vmul(e.npe, -1);                                          // :129-150
+            const double c = dot(nh, V);
+            const double IOR = o.ior;
+            const double delta = (IOR * c) * (IOR * c) - IOR * IOR + 1;
+            n_secondary += 1;
+            if (delta > 0) {
+                d3 T = vadd(vmul(V, -IOR), vmul(nh, IOR * c - sqrt(delta)));
+                e = mkview(ph, normalize(T));
+                outside = 1;
+            } else {
+                e = mkview(ph, vsub(e.npe, vmul(vmul(nh, 2), dot(nh, e.npe))));
+                outside = (outside <= -5) ? 1 : outside - 1;                       // :144-146
+            }
+            to_child = true;
+        }
+        if (to_child) continue;
+        // ---- a call has returned `value`: hand it to the callers that wait
+        bool resumed = false;
+        while (n_ops > 0) {
+            const uint32_t what = op_what[n_ops - 1], kind = what >> 30;
+            const int pobj = (int)(what & 0x3fffffffu);
+            const DObject &po = s.objects[pobj];
+            const uint32_t pclr = op_clr[n_ops - 1];
+            if (kind == OP_REFRACT) {
+                value = cadd(cmul(pclr, po.fresnel), cmul(value, 1 - po.fresnel)); // :127
+                n_ops -= 1;
+            } else {
+                value = cadd(cmul(pclr, 1 - po.ks), cmul(value, po.ks));           // :109
+                if (kind == OP_MIRROR) { n_ops -= 1; continue; }
+                // the second child: the refracted ray, from what the node left behind
+                op_clr[n_ops - 1] = value;
+                op_what[n_ops - 1] = (uint32_t)pobj | OP_REFRACT << 30;
+                const RefractSpawn &sp = spawn[--n_spawn];
+                const d3 V = vmul(sp.npe, -1);
+                const double c = dot(sp.nh, V);
+                const double IOR = 1 / po.ior;
+                d3 T = vadd(vmul(V, -IOR), vmul(sp.nh, IOR * c - sqrt((IOR * c) * (IOR * c) - IOR * IOR + 1)));
+                e = mkview(sp.ph, normalize(T));
+                outside = -1; oi = sp.obj; times = sp.times; ktotal = sp.ktotal;
+                n_secondary += 1;
+                resumed = true;
+                break;
+            }
+        }
+        if (!resumed) break;
+    }
+    store_pixel(pixmap, f, w, rid, x, y, value);
+    } while (0);
+    wave_count(w.counters, 4, n_hit);
+    wave_count(w.counters, 0, n_shadow);
+    wave_count(w.counters, 1, n_eval);
+    wave_count(w.counters, 2, n_over);
+    wave_count(w.counters, 6, n_secondary);
+    wave_count(w.counters, 14, n_deep);
+}
+
 // CalcSubPixel2 (main.cpp:163-209), the renderer HEAD of the reference selects: the closest hit as in
 // CalcSubPixel, coloured by one of the gather shaders -- shading3 (colour bleeding, shader.h:143-191) or
 // shading2 (ambient occlusion, shader.h:100-140).  Both turn the scene's direction set by two random angles
@@ -2327,6 +2536,7 @@ struct rt355_scene {
     int n_padded = 0;
     bool has_tris = false;
     bool reflective = false; // some object has ks != 0
+    bool refractive = false; // some object has fresnel < 1
     double rmax = 0;   // largest sphere radius / triangle bounding radius
     double extent = 0; // largest |coordinate| of a sphere centre or triangle vertex
     // owned device allocations of the scene
@@ -2547,14 +2757,13 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     std::vector<int32_t> prim_obj, prim_tri, by_kind[5]; // planes, spheres, triangles, environments, quadrics
     std::vector<DQuadric> quadrics;
     std::vector<double4> prim_rec;
-    bool any_ks = false;
+    bool any_ks = false, any_glass = false;
     double rmax = 0, extent = 0, ks_abs_max = 0;
     for (int i = 0; i < d->n_objects; i++) {
         const rt355_object &o = d->objects[i];
         if (o.type < RT355_OBJ_PLANE || o.type > RT355_OBJ_QUADRIC)
             return fail(RT355_ERR_ARG, "object " + std::to_string(i) + ": type is one of RT355_OBJ_*");
-        if (o.fresnel != 1)
-            return fail(RT355_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": fresnel != 1 (refraction, main.cpp:116-154, is not accelerated)");
+        if (o.fresnel < 1) any_glass = true; // (main.cpp:117: any other value, NaN included, never refracts)
         if (o.ks != 0) any_ks = true;
         ks_abs_max = std::max(ks_abs_max, std::isfinite(o.ks) ? fabs(o.ks) : 1e300);
         if (o.texture_type < 0 || o.texture_type > 3)
@@ -2569,7 +2778,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
         memcpy(q.n0, o.n0, sizeof q.n0); memcpy(q.n1, o.n1, sizeof q.n1); memcpy(q.n2, o.n2, sizeof q.n2);
         if (o.type == RT355_OBJ_PLANE) put3(q.n1, hcross(H3(o.n0), H3(o.n))); // Plane ctor, anyobject.h:57
         q.radius = o.radius;
-        q.ks = o.ks;
+        q.ks = o.ks; q.fresnel = o.fresnel; q.ior = o.ior;
         q.type = o.type; q.texture_type = o.texture_type; q.tex0 = o.tex0; q.tex1 = o.tex1;
         q.tri_begin = o.tri_begin; q.tri_count = o.tri_count;
         q.rgb = pack_rgb(o.rgb);
@@ -2670,6 +2879,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->tables.n_prims_pad = std::max(256, (sc->view.n_prims + 255) / 256 * 256);
     sc->has_tris = d->n_triangles > 0;
     sc->reflective = any_ks;
+    sc->refractive = any_glass;
     sc->ks_abs_max = ks_abs_max;
     sc->rmax = rmax; sc->extent = extent;
     if (sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri))) {
@@ -2854,7 +3064,10 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     // Mirror rays on a searched scene: the frame is rendered level by level.  A chain goes on while the product
     // of the ks it met is >= 0.05 and it has at most three mirror rays (main.cpp:27-28,103), so the largest |ks|
     // of the scene bounds the number of levels.
-    const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS;
+    // refraction (Shader::shading's renderer only: CalcSubPixel2 does not recurse) is rendered unsearched, one
+    // thread per pixel walking its whole tree of rays
+    const bool refract = sc->refractive && opts->shading == RT355_SHADING_LIGHTS;
+    const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
     int extra_levels = 0;
     if (can_search && sc->reflective && opts->shading == RT355_SHADING_LIGHTS) {
         double k = 1.0;
@@ -3063,7 +3276,9 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         }
 #undef LAUNCH_GATHER
 #define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
-        else if (sc->reflective) {
+        else if (refract) {
+            hipLaunchKernelGGL(k_render_refract, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+        } else if (sc->reflective) {
             if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(true, true); else LAUNCH_DIRECT(true, false);
         } else {
             if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(false, true); else LAUNCH_DIRECT(false, false);
@@ -3218,6 +3433,8 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     unsigned long long ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < COUNTER_SHARDS; i++)
         for (int j = 0; j < 8; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
+    unsigned long long too_deep = 0;
+    for (int i = 0; i < COUNTER_SHARDS; i++) too_deep += shards[i * COUNTER_STRIDE + 14];
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
     sc->search_ms = 0;
@@ -3269,6 +3486,9 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
                 (double)ctr[3] / (double)std::max(1ull, shards[9]), shards[8]);
 #endif
     }
+    if (too_deep)
+        return fail(RT355_ERR_UNSUPPORTED, std::to_string(too_deep) + " pixel(s) whose chain of refracted rays did not end within " +
+                    std::to_string(REFRACT_OPS) + " waiting calls of CalcSubPixel (main.cpp:126,138,148 bound nothing: the reference's recursion would not end either)");
     return RT355_OK;
 }
 

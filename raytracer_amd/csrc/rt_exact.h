@@ -76,6 +76,7 @@ struct DObject { // one entry of Scene::objs, as uploaded
     uint32_t rgb; // 0x00BBGGRR
     int32_t pad_;
     double ks;    // reflection coefficient (anyobject.h:22)
+    double fresnel, ior; // anyobject.h:20-21 (refraction, main.cpp:116-154)
 };
 struct DQuadric { // Quadric (anyobject.h:231-350): its members, and the constants its formulas divide out every call
     double pc[3], n0[3], n1[3], n2[3]; // pCenter, nCoor[0..2]

@@ -363,10 +363,45 @@ def small_case(name: str):
             s.objects.extend(sp.objects)
             return s, Shader(ring_lights(3), 0x101010, 0xDDDDDD, 0x202020), default_camera(w, h), w, h
         return s, default_shader(2), default_camera(w, h), w, h
+    if name == "glass":
+        # refraction (main.cpp:116-154): the reference's scene with both spheres of glass, one of them a mirror
+        # too, in a closed room like main()'s six planes (a ray that leaves a glass object and hits nothing never
+        # ends in the reference: it goes on from the origin with the glass object's coefficients, main.cpp:94,116)
+        w, h = 160, 120
+        s = default_scene()
+        s.add_plane((-40, 0, 0), (1, 0, 0), (0, 1, 0), (220, 180, 180))
+        s.add_plane((40, 0, 0), (-1, 0, 0), (0, 1, 0), (180, 220, 180))
+        s.add_plane((0, 0, 45), (0, 0, -1), (1, 0, 0), (180, 180, 220))
+        s.add_plane((0, -70, 0), (0, 1, 0), (1, 0, 0), (210, 210, 170))
+        s.objects[0]["ks"] = 0.3
+        s.objects[2]["fresnel"] = 0.2; s.objects[2]["ior"] = 1.5; s.objects[2]["ks"] = 0.3
+        s.objects[3]["fresnel"] = 0.6; s.objects[3]["ior"] = 1.33; s.objects[3]["ks"] = 0.5
+        return s, default_shader(2), default_camera(w, h), w, h
+    if name == "glass_mixed":
+        # glass of every kind inside an Environment (so that every ray ends somewhere): a pane (a Plane), an
+        # ellipsoid, a paraboloid, a mesh (whose inside call never hits, anyobject.h:499,659), a textured sphere,
+        # a nearly index-matched sphere
+        w, h = 128, 96
+        s = Scene()
+        s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230), ks=0.2)
+        pane = s.add_plane((0, 4, 0), (0.1, -1, 0.05), (1, 0, 0), (200, 220, 255), ks=0.1)
+        ax = (_n((1, 0.1, 0)), _n((-0.1, 1, 0.2)), _n((0, -0.2, 1)))
+        ell = s.add_quadric("Ellipsoid", (-12, 12, 0), *ax, (6, 4, 8), (200, 90, 90), ks=0.4)
+        par = s.add_quadric("EllipticParaboloid", (12, 16, -9), *ax, (2, 2, 0.4), (220, 200, 80))
+        msh = s.add_mesh(heightfield_tris(5, 5, seed=9, x0=-6, x1=6, y0=8, y1=16, zbase=-6, amp=2.0), ks=0.2)
+        sp1 = s.add_sphere((8, 0, -4), 5, (100, 200, 100), ks=0.3)
+        sp2 = s.add_sphere((-7, -2, -6), 3.5, (210, 210, 100))
+        s.add_texture(sp1, _small_texture(32, 16, 33), 1, 1); s.add_texture(sp1, _small_texture(32, 16, 34), 1, 1)
+        s.set_texture_type(sp1, 1)
+        env = s.add_environment((0, 0, 0), 300, (120, 160, 240), ks=0.1)
+        for o, fr, ior in ((pane, 0.3, 1.5), (ell, 0.25, 1.4), (par, 0.5, 1.2), (msh, 0.5, 1.3), (sp1, 0.4, 1.6),
+                           (sp2, 0.1, 1.05)):
+            s.objects[o]["fresnel"] = fr; s.objects[o]["ior"] = ior
+        return s, default_shader(2), default_camera(w, h), w, h
     raise KeyError(name)
 
 
 SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
                "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside", "mirrors", "mirrors_mesh",
                "environment", "environment_spheres", "solid_texture", "function_3d",
-               "quadrics", "quadrics_spheres"]
+               "quadrics", "quadrics_spheres", "glass", "glass_mixed"]

@@ -307,10 +307,17 @@ def test_full_size_gather(api, oracle):
 
 
 def test_error_behaviour(api):
-    sc = S.default_scene()
-    sc.objects[2]["fresnel"] = 0.5
-    with pytest.raises(api.Rt355Error, match="UNSUPPORTED"):
-        api.Renderer(sc)
+    # a glass sphere alone: a ray that leaves it and hits nothing goes on from the origin with its coefficients
+    # for ever (main.cpp:94,116) -- the reference overflows its stack (the checker and the harness around the
+    # reference's classes both stop at a depth of 2000), the library reports the frame
+    sc = S.Scene()
+    sc.add_sphere((0, 10, 0), 6, (100, 200, 100))
+    sc.objects[0]["fresnel"] = 0.5; sc.objects[0]["ior"] = 1.5
+    r = api.Renderer(sc)
+    with pytest.raises(api.Rt355Error, match="did not end"):
+        r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48)
+    got, _ = r.render(S.default_camera(64, 48), S.default_shader(1), 64, 48, shading=B.SHADING_OCCLUSION)  # no recursion there
+    r.close()
     sc = S.default_scene()
     sc.set_texture_type(2, 4)
     with pytest.raises(api.Rt355Error, match="texture_type"):
@@ -555,6 +562,38 @@ def test_random_scenes_with_quadrics(api, oracle, seed):
             _compare(got, want)
             assert st["gather_rays"] == wst["gather_rays"]
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(50, 56))
+def test_random_glass_in_a_room(api, oracle, seed):
+    """Refraction (main.cpp:116-154): the random scenes closed by an Environment, with random objects of glass
+    (spheres, planes, meshes, quadrics; fresnel 0..0.9, IOR 1.05..1.8, some of them mirrors too).  Every mode
+    renders such a scene unsearched, one thread per pixel; frame and ray counts against the checker, which is
+    pinned on the reference's own classes by the fixtures `glass` and `glass_mixed`."""
+    sc, sh, cam, w, h = _random_case(seed)
+    rng = S.SplitMix64(6161 + seed)
+    sc.add_quadric("Ellipsoid", (rng.uniform(-10, 10), rng.uniform(5, 20), rng.uniform(-5, 5)), (1, 0, 0), (0, 1, 0), (0, 0, 1),
+                   (rng.uniform(2, 5), rng.uniform(2, 5), rng.uniform(2, 5)), (200, 120, 90))
+    sc.add_environment((0, 10, 0), 400, (110, 150, 235))
+    n_glass = 0
+    for i, o in enumerate(sc.objects[:-1]):
+        if rng.uniform() < 0.25 or i == len(sc.objects) - 2:
+            o["fresnel"] = rng.uniform(0.0, 0.9); o["ior"] = rng.uniform(1.05, 1.8)
+            if rng.uniform() < 0.4:
+                o["ks"] = rng.uniform(0.2, 0.9)
+            n_glass += 1
+    assert n_glass > 0
+    w, h = 80, 60
+    cam = B.camera(tuple(cam.p_eye), tuple(cam.v_view), (0, 0, 1), 10.0, w, h)
+    for alias in (0, 2):
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=seed), threads=0)
+        r = api.Renderer(sc)
+        for mode in (B.MODE_PACKET, B.MODE_BRUTE):
+            got, st = r.render(cam, sh, w, h, mode=mode, alias=alias, seed=seed)
+            _compare(got, want)
+            assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"] > 0, mode
+        r.close()
 
 
 @pytest.mark.gpu
