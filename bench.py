@@ -64,6 +64,11 @@ def build_workload(name: str):
             elif i % 3 == 0:
                 o["ks"] = 0.9 if i % 9 == 0 else 0.5
         return sc, S.spheres_shader(8), S.default_camera(w, h), w, h
+    if name == "glass_room_4k":
+        # refraction (main.cpp:116-154): the reference's two spheres of glass, one a mirror too, in a closed room
+        w, h = 3840, 2160
+        sc, sh, _, _, _ = S.small_case("glass")
+        return sc, sh, S.default_camera(w, h), w, h
     if name == "mesh1m_2lights_8k":
         w, h = 7680, 4320
         return S.mesh_scene(1_000_000, seed=356), S.mesh_shader(), S.default_camera(w, h), w, h
@@ -129,7 +134,7 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None
     rays = count(st)
     out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
-                     f"{st['shadow_rays']} shadow + {st['gather_rays']} gather rays, {dt:.2f} s)"}
+                     f"{st['shadow_rays']} shadow + {st['gather_rays']} gather + {st['secondary_rays']} mirror or refracted rays, {dt:.2f} s)"}
     # one thread of the same port, on a sample a thread finishes in seconds
     s1 = stride * (4 if scene.n_primitives >= 1000 else 1)
     t0 = time.perf_counter()
@@ -152,7 +157,7 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None
         out["reference_classes_one_thread"] = {
             "value": count(sts) / dtr / 1e6, "unit": "Mrays/s", "kind": "reference",
             "sample": f"rows {h // 2}..{h // 2 + rows - 1} of the same frame ({sts['primary_rays']} primary + "
-                      f"{sts['shadow_rays']} shadow + {sts['gather_rays']} gather rays, {dtr:.2f} s); the harness "
+                      f"{sts['shadow_rays']} shadow + {sts['gather_rays']} gather + {sts['secondary_rays']} mirror or refracted rays, {dtr:.2f} s); the harness "
                       f"compiles the reference's headers, main.cpp itself needs GLUT"}
     return out
 
@@ -321,12 +326,14 @@ def measure(name, args, ctx, headline):
         flops = algorithmic_flops(scene, shader, cam, stats)
         avg_ms = acc["primary_ms"] / K
         tf = flops / (avg_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_gather" if shading else "k_render_direct", "achieved": round(tf, 3),
+        refracts = bool((scene.pack().objects["fresnel"] < 1).any()) and not shading
+        out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_gather" if shading else ("k_render_refract" if refracts else "k_render_direct"), "achieved": round(tf, 3),
                            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 5),
                            "traffic": None, "launches_per_frame": 1, "avg_launch_ms": round(avg_ms, 4),
                            "algorithmic_flops_per_frame": flops, "flops_per_test": ALGO_FLOPS,
                            "algorithmic_bytes_per_frame": float(3 * w * h),
-                           "note": "arithmetic is fp64 (half the fp32 rate); per-hit shading is not in the flop count"}
+                           "note": "arithmetic is fp64 (half the fp32 rate); per-hit shading is not in the flop count"
+                                   + ("; nor are the tests of the mirror and refracted rays" if stats["secondary_rays"] else "")}
     else:
         rooflines = {"k_resolve_primary": hbm_roofline("k_resolve_primary", primary_bytes(stats, n_rays_padded, nl, True),
                                                        acc["primary_ms"], K)}
@@ -376,7 +383,8 @@ def measure(name, args, ctx, headline):
 
 
 HEADLINE = "default_4k"
-OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "default_bleed162_4k", "spheres10k_mirrors_8lights_4k"]
+OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "default_bleed162_4k", "spheres10k_mirrors_8lights_4k",
+          "glass_room_4k"]
 
 
 def main():

@@ -53,8 +53,8 @@ typedef struct rt355_object {
     double n2[3];     /* Sphere::n2 (:105)                                                   */
     double radius;    /* Sphere::radius (:102)                                               */
     double ks;        /* AnyObject::ks (:22): reflection coefficient (main.cpp:93-112)                       */
-    double fresnel;   /* AnyObject::fresnel (:21); must be 1 (no refraction yet)             */
-    double ior;       /* AnyObject::IOR (:20); carried, unused while fresnel == 1            */
+    double fresnel;   /* AnyObject::fresnel (:21): < 1 refracts (main.cpp:116-154)            */
+    double ior;       /* AnyObject::IOR (:20), read when fresnel < 1                          */
     int32_t type;     /* RT355_OBJ_*                                                         */
     int32_t texture_type; /* AnyObject::texture_type (:29): 0 flat colour, 1 texture mapping (shader.h:53-58),
                              2 solid texture: textures[0] and [1] projected along textures[0]'s n2
