@@ -64,6 +64,10 @@ def build_workload(name: str):
             elif i % 3 == 0:
                 o["ks"] = 0.9 if i % 9 == 0 else 0.5
         return sc, S.spheres_shader(8), S.default_camera(w, h), w, h
+    if name == "default_mirrors_4k":  # the reference's scene with reflecting objects (main.cpp:93-112), unsearched
+        w, h = 3840, 2160
+        sc, sh, _, _, _ = S.small_case("mirrors")
+        return sc, sh, S.default_camera(w, h), w, h
     if name == "glass_room_4k":
         # refraction (main.cpp:116-154): the reference's two spheres of glass, one a mirror too, in a closed room
         w, h = 3840, 2160

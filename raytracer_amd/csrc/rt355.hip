@@ -1703,8 +1703,9 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
 // deepest.  On a miss the reference goes on with objs[0]'s ks, a zero hit point and a zero normal; so does
 // this.  Compiled apart so that scenes without mirrors do not carry the loop, and (ENV) scenes without an
 // Environment not its tests.
+// (REFLECT: three waves per SIMD -- left alone the compiler takes 207 registers, two waves, and 26 % longer)
 template <bool REFLECT, bool ENV>
-__global__ __launch_bounds__(256) void k_render_direct(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+__global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                        unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0;
@@ -1846,7 +1847,8 @@ __device__ __forceinline__ void intersect_inside(const SceneView &s, int obj, co
     // mesh then drops (t_min > 0, :659): always the miss tuple, point and normal zero (:664)
     *ph_out = ph; *nh_out = nh;
 }
-__global__ __launch_bounds__(256) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+// (three waves per SIMD: at the two the compiler picks by itself the frame takes 30 % longer, at four the spills cost more)
+__global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                         unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0, n_deep = 0;

@@ -440,7 +440,7 @@ __device__ __forceinline__ void solid_texture(const SceneView &s, const DObject 
 // Texture::Get3DFunction(ph, Point3D(0, 0, 20)), texture.h:164-177 as shader.h:66 calls it: bands by the sign
 // of sin(0.3 pi (|v x (1,0,0)| + v . (1,0,0))), v = (ph - centre) without its y.  Only the sign of the sine is
 // used, and any sine with a relative error bound has the right sign (sin is zero at no double but 0).
-__device__ __forceinline__ uint32_t function_3d(d3 ph) {
+__device__ __noinline__ uint32_t function_3d(d3 ph) { // (out of line: rare, and its sine costs every caller registers)
     const d3 v = vsub(ph, D3(0, 0, 20));
     const d3 u = D3(v.x, 0, v.z), w = D3(1, 0, 0);
     const d3 c = D3(u.y * w.z - u.z * w.y, u.z * w.x - u.x * w.z, u.x * w.y - u.y * w.x); // vector3D.h:94-96
