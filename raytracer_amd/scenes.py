@@ -398,10 +398,39 @@ def small_case(name: str):
                            (sp2, 0.1, 1.05)):
             s.objects[o]["fresnel"] = fr; s.objects[o]["ior"] = ior
         return s, default_shader(2), default_camera(w, h), w, h
+    if name == "main_all":
+        # everything main() constructs (main.cpp:547-617), the objects it leaves out of the list at HEAD pushed
+        # too: six planes, three spheres (sphere3 a perfect mirror with the 3D-function texture), the textured
+        # Environment, two meshes with ks = 1 (height fields stand in for geodesic.obj and dodecahandle.obj, which
+        # the repository does not hold), both lights of main.cpp:623-624
+        w, h = 160, 120
+        s = Scene()
+        s.add_plane((0, 13, 0), (0, -1, 0), (-1, 0, 0), (200, 200, 200))
+        s.add_plane((0, -100, 0), (0, 1, 0), (-1, 0, 0), (214, 147, 44))
+        s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+        s.add_plane((0, 0, 100), (0, 0, -1), (1, 0, 0), (255, 0, 0))
+        s.add_plane((100, 0, 0), (-1, 0, 0), (0, 1, 0), (0, 255, 0))
+        s.add_plane((-100, 0, 0), (1, 0, 0), (0, 1, 0), (0, 255, 0))
+        s.add_sphere((-10.5, 0, 0), 10, (100, 200, 100))
+        s.add_sphere((10.5, 0, 0), 10, (200, 100, 100))
+        s3 = s.add_sphere((-20, -20, 20), 10, (73, 179, 248), ks=1)
+        s.add_texture(s3, _small_texture(16, 16, 3), 0.5, 0.5); s.add_texture(s3, _small_texture(16, 16, 3), 0.5, 0.5)
+        s.set_texture_type(s3, 3)
+        env = s.add_environment((0, -50, 20), 1000, (255, 255, 0), (-1, 1, 0), (-1, -1, 0), (0, 0, 1))
+        s.add_texture(env, _small_texture(64, 32, 4), 1, 1); s.add_texture(env, _small_texture(64, 32, 4), 1, 1)
+        s.set_texture_type(env, 1)
+        m1 = s.add_mesh(heightfield_tris(5, 5, seed=11, x0=-8, x1=8, y0=-12, y1=-4, zbase=2, amp=3.0), ks=1)
+        s.objects[m1]["ior"] = 1.1
+        s.add_texture(m1, _small_texture(16, 16, 5), 0.1, 0.1); s.add_texture(m1, _small_texture(16, 16, 6), 0.1, 0.1)
+        m2 = s.add_mesh(heightfield_tris(4, 4, seed=12, x0=-26, x1=-14, y0=-34, y1=-26, zbase=14, amp=2.0), ks=1)
+        s.add_texture(m2, _small_texture(16, 16, 5), 1, 1); s.add_texture(m2, _small_texture(16, 16, 5), 1, 1)
+        s.set_texture_type(m2, 1)
+        lights = [light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 1, 1)), light_src(3, (30, -30, 50), (0, 0, -1), (1, 1, 1))]
+        return s, Shader(lights, 0x000000, 0xDDDDDD, 0x000000), default_camera(w, h), w, h
     raise KeyError(name)
 
 
 SMALL_CASES = ["default_1light", "default_2lights", "no_lights", "empty_scene", "textured", "mesh",
                "mesh_flat", "spheres300", "spheres300_dir", "mesh_dir", "inside", "mirrors", "mirrors_mesh",
                "environment", "environment_spheres", "solid_texture", "function_3d",
-               "quadrics", "quadrics_spheres", "glass", "glass_mixed"]
+               "quadrics", "quadrics_spheres", "glass", "glass_mixed", "main_all"]
