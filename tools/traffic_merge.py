@@ -10,7 +10,7 @@ import sys
 def table(path, counter):
     out = {}
     for line in open(path):
-        m = re.match(r"^(?:void )?(k_\w+)(?:<[^>]*>)?\s+" + counter + r"\s+(\d+)\s+(\d+)\s+(\d+)\s*$", line)
+        m = re.match(r"^(?:void )?(k_\w+)(?:<[^>]*>?)?\s+" + counter + r"\s+(\d+)\s+(\d+)\s+(\d+)\s*$", line)
         if m:
             name, total, n = m.group(1), int(m.group(2)), int(m.group(3))
             cur = out.setdefault(name, [0, 0])
