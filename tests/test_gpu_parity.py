@@ -402,6 +402,47 @@ def test_cpp_host_demo_matches_checker(api, oracle, tmp_path):
     _compare(got, want)
 
 
+def test_cpp_host_classes_of_every_kind(api, oracle, tmp_path):
+    """The C++ host's mirror of the reference's classes beyond main()'s four objects: its `all` scene (main()'s
+    whole object list plus a glass sphere, a solid texture with its own projector read from a BMP file, an
+    Ellipsoid and a Cylinder) against the same scene built through the Python host and rendered by the checker."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracer_amd", "host", "rt355_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    tex = S._small_texture(32, 16, 77)
+    bmp = tmp_path / "picture.bmp"
+    B.write_bmp(str(bmp), tex)
+    prefix = str(tmp_path / "all")
+    subprocess.run([exe, "200", "150", "2", prefix, "all", str(bmp)], check=True, timeout=100)
+    got = np.fromfile(prefix + ".rgb", dtype=np.uint8).reshape(150, 200, 3)
+    n = B._normalize
+    s = S.Scene()
+    s.add_plane((0, 13, 0), (0, -1, 0), (-1, 0, 0), (200, 200, 200))
+    s.add_plane((0, -100, 0), (0, 1, 0), (-1, 0, 0), (214, 147, 44))
+    s.add_plane((0, 0, -10), (0, 0, 1), (1, 0, 0), (230, 230, 230))
+    s.add_plane((0, 0, 100), (0, 0, -1), (1, 0, 0), (255, 0, 0))
+    s.add_plane((100, 0, 0), (-1, 0, 0), (0, 1, 0), (0, 255, 0))
+    s.add_plane((-100, 0, 0), (1, 0, 0), (0, 1, 0), (0, 255, 0))
+    s1 = s.add_sphere((-10.5, 0, 0), 10, (100, 200, 100))
+    frame = (n((1, 0.2, 0)), n((-0.1, 0.1, 1)), n((0.1, -1, 0.2)), (-8, 0, 2))
+    s.add_texture(s1, tex, 24.0, 18.0, frame=frame); s.add_texture(s1, tex, 24.0, 18.0, frame=frame)
+    s.set_texture_type(s1, 2)
+    s2 = s.add_sphere((10.5, 0, 0), 10, (200, 100, 100), ks=0.3)
+    s.objects[s2]["fresnel"] = 0.3; s.objects[s2]["ior"] = 1.5
+    s3 = s.add_sphere((-20, -20, 20), 10, (73, 179, 248), ks=1)
+    s.add_texture(s3, tex, 0.5, 0.5); s.add_texture(s3, tex, 0.5, 0.5)
+    s.set_texture_type(s3, 3)
+    env = s.add_environment((0, -50, 20), 1000, (255, 255, 0), (-1, 1, 0), (-1, -1, 0), (0, 0, 1))
+    s.add_texture(env, tex, 1, 1); s.add_texture(env, tex, 1, 1)
+    s.set_texture_type(env, 1)
+    s.add_quadric("Ellipsoid", (0, -6, -5), (1, 0, 0), (0, 1, 0), (0, 0, 1), (4, 2.5, 3), (220, 200, 80), ks=0.2)
+    s.add_quadric("Cylinder", (30, 5, 0), n((1, 0.1, 0)), n((-0.1, 1, 0.2)), n((0, -0.2, 1)), (2.2, 2.2, 1), (90, 200, 90))
+    want, wst = oracle.render(s.pack(), S.default_camera(200, 150), S.default_shader(2), B.opts(200, 150), threads=0)
+    assert wst["secondary_rays"] > 0
+    _compare(got, want)
+
+
 def _random_case(seed):
     """A random mix of planes, spheres and meshes lit by random lights of every type."""
     rng = S.SplitMix64(9000 + seed)
