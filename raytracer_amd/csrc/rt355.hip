@@ -86,6 +86,7 @@ __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, u
 #define CAND_ENVIRONMENT (CAND_SPHERE | CAND_TRI) // both bits: an Environment (its record is a sphere's)
 #define REC_QUADRIC (-2) // neither bit: a plane or a quadric, told apart by the second int of the record (-1 | -2)
 #define CAND_INDEX 0x3fffffffu
+#define FAR_ORIGIN 1e15 // L1 norm of a ray origin beyond which the ray is not searched in fp32 but tested against everything
 #define CAND_UNSEARCHED 0xffffffffu // candidate count of a ray the search left to the fp64 walk over everything
 #ifndef CAND_BATCH
 #define CAND_BATCH 2        // candidates whose ids and records are loaded together by the exact tests
@@ -421,7 +422,10 @@ __device__ __forceinline__ Bound bound_of_wave(int kind, float4 p, float st) {
 __device__ __forceinline__ float4 bundle_ray(const Bundle &bd, d3 ph, d3 nhl) {
     if (bd.kind == 1) return make_float4((float)nhl.x, (float)nhl.y, (float)nhl.z, 0.f);
     double pu = dot(ph, bd.e1), pv = dot(ph, bd.e2);
-    double er = RT_EPS22 * (fabs(pu) + fabs(pv));
+    // ... and the reference's own rounding: from an origin far along the common direction (a mirror ray's hit on an
+    // unbounded quadric or plane can lie 1e19 away) Sphere::CalcIntersect's B * B - C cancels to noise of
+    // ~2e-8 |pe - c| in the distance it can tell from the radius, so spheres that far off the line may "hit"
+    double er = RT_EPS22 * (fabs(pu) + fabs(pv)) + 1.2e-7 * fabs(dot(ph, bd.dir));
     double msq = (2.0 * bd.rmaxp * er + er * er) * (1.0 + 1e-5);
     return make_float4((float)pu, (float)pv, (float)(msq * (1.0 + 1e-6)), (float)(4.0 * er));
 }
@@ -1313,7 +1317,7 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
         ox = (float)ray_d[0 * n + rid]; oy = (float)ray_d[1 * n + rid]; oz = (float)ray_d[2 * n + rid];
         ux = (float)ray_d[3 * n + rid]; uy = (float)ray_d[4 * n + rid]; uz = (float)ray_d[5 * n + rid];
         const float ul = ux * ux + uy * uy + uz * uz, ol = fabsf(ox) + fabsf(oy) + fabsf(oz);
-        odd = !(ul > 0.99f && ul < 1.01f) || !(ol < 1e15f);
+        odd = !(ul > 0.99f && ul < 1.01f) || !(ol < (float)FAR_ORIGIN);
     }
     const bool in_beam = active && !odd;
     const float n_in = wave_sum_f(in_beam ? 1.0f : 0.0f);
@@ -2416,13 +2420,18 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     }
     h.border_w = h.no_border ? 0.0 : w.rec_d[9 * n + rid];
     uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
+    // A hit this far out (a mirror ray that ran along an unbounded quadric or plane: 1e19 happens) has left the
+    // range in which the fp32 search means anything -- squares overflow, and at such a distance the reference's
+    // own formulas answer with rounding noise, which no geometric bound predicts.  Its shadow rays are tested
+    // against everything, as the reference tests them.
+    const bool far = !(fabs(ph.x) + fabs(ph.y) + fabs(ph.z) < FAR_ORIGIN);
     for (int g = 0; g < cur.count; g++) {
         sum = shade_light(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
             Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_STRIDE(n); sp.count = w.spill.count + g;
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
-            return nearest_occluder(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+            return nearest_occluder(s, sr, cur.b[g].kind == 0 || far, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
                                     w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
         }, unused);
     }

@@ -567,7 +567,7 @@ def test_random_scenes_inside_an_environment(api, oracle, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(40, 48))
+@pytest.mark.parametrize("seed", list(range(40, 48)) + [1822])  # 1822: a mirror chain along a paraboloid, hits 1e19 away
 def test_random_scenes_with_quadrics(api, oracle, seed):
     """The random scenes with two to four random quadrics (anyobject.h:231-442: the five subclasses, the default
     "plane" and general integer coefficients, axes neither unit nor orthogonal, float scales), some of them
@@ -628,7 +628,14 @@ def test_random_glass_in_a_room(api, oracle, seed):
     w, h = 80, 60
     cam = B.camera(tuple(cam.p_eye), tuple(cam.v_view), (0, 0, 1), 10.0, w, h)
     for alias in (0, 2):
-        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=seed), threads=0)
+        try:
+            want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=seed), threads=0)
+        except RuntimeError:   # a chain that does not end (the checker stops at depth 2000): the library must say so too
+            r = api.Renderer(sc)
+            with pytest.raises(api.Rt355Error, match="did not end"):
+                r.render(cam, sh, w, h, alias=alias, seed=seed)
+            r.close()
+            continue
         r = api.Renderer(sc)
         for mode in (B.MODE_PACKET, B.MODE_BRUTE):
             got, st = r.render(cam, sh, w, h, mode=mode, alias=alias, seed=seed)
