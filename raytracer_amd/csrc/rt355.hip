@@ -86,7 +86,14 @@ __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, u
 #define CAND_ENVIRONMENT (CAND_SPHERE | CAND_TRI) // both bits: an Environment (its record is a sphere's)
 #define REC_QUADRIC (-2) // neither bit: a plane or a quadric, told apart by the second int of the record (-1 | -2)
 #define CAND_INDEX 0x3fffffffu
-#define FAR_ORIGIN 1e15 // L1 norm of a ray origin beyond which the ray is not searched in fp32 but tested against everything
+// A ray that starts far from the scene (a mirror ray's hit on an unbounded quadric or plane can lie 1e19 away)
+// is not searched: Sphere::CalcIntersect's B * B - C cancels to noise there -- from a distance D it cannot tell
+// a line that touches the sphere from one that passes ~2e-8 D beside it -- so the reference "hits" spheres no
+// geometric bound predicts, and beyond 1e15 fp32 squares overflow besides.  Such a ray is tested against
+// everything, as the reference tests it.  The limit is FAR_SCALE times the size of the scene (bounded
+// primitives), where that noise reaches a thousandth of the scene's size; capped at FAR_ORIGIN.
+#define FAR_ORIGIN 1e15
+#define FAR_SCALE 1e5
 #define CAND_UNSEARCHED 0xffffffffu // candidate count of a ray the search left to the fp64 walk over everything
 #ifndef CAND_BATCH
 #define CAND_BATCH 2        // candidates whose ids and records are loaded together by the exact tests
@@ -1226,6 +1233,7 @@ struct GeneralTable {
     const uint32_t *plane_id;// [n_planes] candidate ids of the planes
     int32_t n_supers, n_planes;
     float tight_rho, tight_theta; // a wave whose origin ball and cone are within these searches as one beam
+    float far_origin;             // SceneView::far_origin
 };
 struct Beam { float cx, cy, cz, rho, ax, ay, az, theta; };
 // may a ray of the beam hit the sphere q?  (NaN q: no)
@@ -1317,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
         ox = (float)ray_d[0 * n + rid]; oy = (float)ray_d[1 * n + rid]; oz = (float)ray_d[2 * n + rid];
         ux = (float)ray_d[3 * n + rid]; uy = (float)ray_d[4 * n + rid]; uz = (float)ray_d[5 * n + rid];
         const float ul = ux * ux + uy * uy + uz * uz, ol = fabsf(ox) + fabsf(oy) + fabsf(oz);
-        odd = !(ul > 0.99f && ul < 1.01f) || !(ol < (float)FAR_ORIGIN);
+        odd = !(ul > 0.99f && ul < 1.01f) || !(ol < t.far_origin);
     }
     const bool in_beam = active && !odd;
     const float n_in = wave_sum_f(in_beam ? 1.0f : 0.0f);
@@ -1532,6 +1540,48 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
         if (!brute && n <= CAND_CAP) evaluated -= n; // walked twice, counted once
     }
     return bt;
+}
+
+// The closest occluder of one ray (the same in every lane) over EVERY primitive, the lanes of the wave sharing
+// the list: what nearest_occluder's walk over everything returns, 64 primitives at a time.  Objects take
+// hits with t >= 0, triangles with t > 0 (a mesh reports its smallest t only if that is > 0); a triangle hit at
+// exactly t = 0 removes its whole mesh, which only the ordered walk knows how to do, so then every lane walks.
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double nearest_occluder_wave(const SceneView &s, const Ray &e, uint32_t rid, uint32_t n_rays) {
+    const int lane = threadIdx.x & 63;
+    const int first_env = s.n_planes + s.n_spheres, first_quadric = first_env + s.n_envs, first_tri = first_quadric + s.n_quadrics;
+    double bt = RT_FLT_MAX;
+    bool zero_tri = false;
+    for (int k = lane; k < s.n_prims; k += 64) {
+        const int prim = s.kind_prims[k];
+        double t;
+        if (k >= first_tri) {
+            int outside; d3 ph; double u, v;
+            t = tri_t(s.tris[s.prim_tri[prim]], e, &outside, &ph, &u, &v);
+            if (t == 0) { zero_tri = true; t = -1; }
+        } else if (k < s.n_planes) {
+            t = plane_t(s.objects[s.prim_obj[prim]], e);
+        } else if (k < first_env) {
+            t = sphere_t_rec(s.prim_rec[prim], e);
+        } else if (k < first_quadric) {
+            int inside;
+            t = environment_t_rec(s.prim_rec[prim], e, &inside);
+        } else {
+            int outside, branch;
+            t = quadric_t(s.quadrics[s.objects[s.prim_obj[prim]].tri_begin], e, &outside, &branch);
+        }
+        if (t >= 0 && t < bt) bt = t;
+    }
+    if (__any(zero_tri)) {
+        Spill none; none.pool = nullptr; none.count = nullptr;
+        uint32_t ev = 0, ov = 0;
+        return nearest_occluder(s, e, true, rid, n_rays, nullptr, nullptr, none, ev, ov);
+    }
+    return wave_min_d(bt);
 }
 
 // the colour of grid point (x, y): a pixel of the frame, or a sub-sample kept for k_average
@@ -2306,7 +2356,9 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_d[3 * n + rid] = nh.x; w.rec_d[4 * n + rid] = nh.y; w.rec_d[5 * n + rid] = nh.z;
     w.rec_d[6 * n + rid] = h.reh.x; w.rec_d[7 * n + rid] = h.reh.y; w.rec_d[8 * n + rid] = h.reh.z;
     if (!h.no_border) w.rec_d[9 * n + rid] = h.border_w;
-    w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u) | (h.emissive ? (1u << 25) : 0u);
+    const bool far = !(fabs(ph.x) + fabs(ph.y) + fabs(ph.z) < s.far_origin); // see FAR_SCALE
+    if (far && !h.emissive && sh.n_lights) atomicAdd(&w.counters[15], 1ull);     // (rare: one atomic per such hit)
+    w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u) | (h.emissive ? (1u << 25) : 0u) | (far ? (1u << 26) : 0u);
     w.rec_cm1[rid] = h.cm1;
     } while (0);
     const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, got_hit && sh.n_lights, ph, nh);
@@ -2379,6 +2431,46 @@ __global__ __launch_bounds__(256) void k_fold_levels(Frame f, Work w, unsigned c
     store_pixel(pixmap, f, w, rid, x, y, clr); // f.level is -1 here: the frame, or the sub-sample sums of k_average
 }
 
+// The shadow rays of the hits far from the scene (bit 26 of their record, see FAR_SCALE) against everything.
+// One lane doing that alone in k_shade_group holds its wave for n_prims tests per light, so it is done here,
+// a wave taking one such hit at a time with its lanes sharing the primitive list; the distances wait in the
+// ray's first two candidate slots of each light.  Frames without such hits leave at the first line.
+__global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, Frame f, Work w, Group cur) {
+    if (w.counters[15] == 0) return;
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_eval = 0;
+    const bool far = rid < f.n_rays && w.rec_obj[rid] >= 0 && ((w.rec_cm0[rid] >> 25) & 3u) == 2u; // far, not emissive
+    d3 fp = D3(0, 0, 0), fn = D3(0, 0, 0);
+    if (far) {
+        const size_t n = f.n_rays;
+        fp = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
+        fn = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+    }
+    unsigned long long todo = __ballot(far);
+    while (todo) { // uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const d3 p = D3(__shfl(fp.x, src, 64), __shfl(fp.y, src, 64), __shfl(fp.z, src, 64));
+        const d3 nrm = D3(__shfl(fn.x, src, 64), __shfl(fn.y, src, 64), __shfl(fn.z, src, 64));
+        const uint32_t src_rid = (uint32_t)__shfl((int)rid, src, 64);
+        for (int g = 0; g < cur.count; g++) {
+            const DLight &L = sh.lights[cur.k0 + g];
+            const d3 nhl = light_nhl(L, p);
+            if (dot(nrm, vmul(nhl, -1)) <= 0) continue;  // no shadow ray (shader.h:396)
+            Ray sr; // as shade_light builds it
+            if (L.type == 0) { sr.pe = p; sr.npe = ld3(L.shadow_dir); }
+            else sr = mkview(p, vmul(nhl, -1));
+            const double t = nearest_occluder_wave(s, sr, src_rid, f.n_rays);
+            if ((int)(threadIdx.x & 63) == src) {
+                uint32_t *slot = w.cand + (size_t)g * CAND_CAP * f.n_rays + rid;
+                slot[0] = (uint32_t)__double2loint(t); slot[f.n_rays] = (uint32_t)__double2hiint(t);
+                n_eval += (uint32_t)s.n_prims;
+            }
+        }
+    }
+    wave_count(w.counters, 1, n_eval);
+}
+
 // Shader::shading's loop over the lights (shader.h:60-94) for the lights of one group: colour before
 // the shadow (shader.h:75-89), CalcShadow on the light's candidates (shader.h:393-433), the running
 // mean (shader.h:93); then either the next group's shadow rays or the pixel store (main.cpp:367-369).
@@ -2414,24 +2506,24 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     const uint32_t cm0w = w.rec_cm0[rid];
     h.cm0 = cm0w & 0xffffffu; h.cm1 = w.rec_cm1[rid];
     h.no_border = (cm0w >> 24) & 1u;
+    const bool far = (cm0w >> 26) & 1u; // its shadow rays were tested against everything by k_shade_far
     if ((cm0w >> 25) & 1u) { // an Environment: its colour as it is (shader.h:70-72)
         if (last) store_pixel(pixmap, f, w, rid, x, y, h.cm0);
         break;
     }
     h.border_w = h.no_border ? 0.0 : w.rec_d[9 * n + rid];
     uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
-    // A hit this far out (a mirror ray that ran along an unbounded quadric or plane: 1e19 happens) has left the
-    // range in which the fp32 search means anything -- squares overflow, and at such a distance the reference's
-    // own formulas answer with rounding noise, which no geometric bound predicts.  Its shadow rays are tested
-    // against everything, as the reference tests them.
-    const bool far = !(fabs(ph.x) + fabs(ph.y) + fabs(ph.z) < FAR_ORIGIN);
     for (int g = 0; g < cur.count; g++) {
         sum = shade_light(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
             Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_STRIDE(n); sp.count = w.spill.count + g;
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
-            return nearest_occluder(s, sr, cur.b[g].kind == 0 || far, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+            if (far) { // found above
+                const uint32_t *slot = w.cand + (size_t)g * CAND_CAP * n + rid;
+                return __hiloint2double((int)slot[n], (int)slot[0]);
+            }
+            return nearest_occluder(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
                                     w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
         }, unused);
     }
@@ -2750,6 +2842,7 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     g.tight_rho = n_groups8 ? (float)(mean_group / (double)n_groups8) : 0.0f;
     g.tight_rho *= 2.0f;
     g.tight_theta = 0.3f;
+    g.far_origin = (float)sc->view.far_origin;
     if (const char *e = getenv("RT355_GENERAL_TIGHT")) { // "rho_factor,theta": tuning aid
         double a = 1, b = 0.2;
         if (sscanf(e, "%lf,%lf", &a, &b) == 2) { g.tight_rho *= (float)a; g.tight_theta = (float)b; }
@@ -2893,6 +2986,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->refractive = any_glass;
     sc->ks_abs_max = ks_abs_max;
     sc->rmax = rmax; sc->extent = extent;
+    sc->view.far_origin = std::min(FAR_ORIGIN, FAR_SCALE * (1.0 + extent + rmax));
     if (sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri))) {
         rt355_scene_destroy(sc);
         return rc;
@@ -3352,6 +3446,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             Group next = group_of(j + 1);
             if ((rc1 = clear_bins(next))) return rc1;
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
+            hipLaunchKernelGGL(k_shade_far, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur);
             hipLaunchKernelGGL(k_shade_group, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
             resolves++;

@@ -273,6 +273,7 @@ struct SceneView { // device pointers of an uploaded scene
                                // in scene-list order
     const DQuadric *quadrics;  // a quadric object's record is quadrics[object.tri_begin]
     int32_t n_objects, n_prims, n_planes, n_spheres, n_envs, n_quadrics;
+    double far_origin;         // L1 norm of a ray origin beyond which the ray is tested against everything (see FAR_SCALE)
 };
 
 __device__ __forceinline__ double prim_t(const SceneView &s, int prim, const Ray &e, int *is_mesh, int *obj_out) {

@@ -567,7 +567,7 @@ def test_random_scenes_inside_an_environment(api, oracle, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(40, 48)) + [1822])  # 1822: a mirror chain along a paraboloid, hits 1e19 away
+@pytest.mark.parametrize("seed", list(range(40, 48)) + [1822, 3248])  # mirror chains along a paraboloid: hits 1e19 and 1e10 away
 def test_random_scenes_with_quadrics(api, oracle, seed):
     """The random scenes with two to four random quadrics (anyobject.h:231-442: the five subclasses, the default
     "plane" and general integer coefficients, axes neither unit nor orthogonal, float scales), some of them
