@@ -1841,7 +1841,7 @@ __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneVie
 // Nothing in the reference bounds the refracted chain -- a ray that leaves a glass object and hits nothing goes
 // on from the origin with that object's coefficients for ever (main.cpp:94,116) and overflows its stack --
 // so a pixel that fills the stack raises counter 14 and the frame is reported as failed.
-#define REFRACT_OPS 64
+#define REFRACT_OPS 256
 #define REFRACT_SPAWNS 4
 #define OP_MIRROR 0u  // value = clr * (1 - ks) + child * ks
 #define OP_REFRACT 1u // value = clr * fresnel + child * (1 - fresnel)
