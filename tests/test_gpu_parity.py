@@ -472,7 +472,8 @@ def _random_case(seed):
     sh = S.Shader(lights, 0x101418, 0xDDDDDD, 0x202020)
     eye = (rng.uniform(-10, 10), rng.uniform(-30, -12), rng.uniform(-4, 12))
     view = (rng.uniform(-0.3, 0.3), 1.0, rng.uniform(-0.3, 0.2))
-    w, h = 112, 80
+    k = int(os.environ.get("RT355_TEST_SCALE", "1"))  # tools/parity_sweep.py renders the same scenes larger
+    w, h = 112 * k, 80 * k
     return sc, sh, B.camera(eye, view, (0, 0, 1), 10.0, w, h), w, h
 
 
@@ -625,7 +626,7 @@ def test_random_glass_in_a_room(api, oracle, seed):
                 o["ks"] = rng.uniform(0.2, 0.9)
             n_glass += 1
     assert n_glass > 0
-    w, h = 80, 60
+    w, h = 80 * w // 112, 60 * w // 112
     cam = B.camera(tuple(cam.p_eye), tuple(cam.v_view), (0, 0, 1), 10.0, w, h)
     for alias in (0, 2):
         try:
