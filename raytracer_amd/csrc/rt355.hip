@@ -1485,16 +1485,18 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
 // over the candidates keeps a minimum and nothing else.  A triangle hit at exactly t = 0 (which removes its
 // mesh, see above), an overflowed list or an unsearched bundle go through closest_hit.
 // the rare cases of nearest_occluder (inlined: a call costs the common case more than the registers do)
+template <bool ENV = true>
 __device__ __forceinline__ double nearest_occluder_general(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                                         uint32_t n_rays, const uint32_t *__restrict__ cand,
                                                         const uint32_t *__restrict__ cand_cnt, const Spill &sp,
                                                         uint32_t *evaluated, uint32_t *overflowed) {
     Closest c;
     uint32_t ev = 0, ov = 0;
-    closest_hit(s, e, brute, rid, n_rays, cand, cand_cnt, sp, c, ev, ov);
+    closest_hit<false, ENV>(s, e, brute, rid, n_rays, cand, cand_cnt, sp, c, ev, ov);
     *evaluated += ev; *overflowed += ov;
     return c.t_best;
 }
+template <bool ENV = true>
 __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                                    uint32_t n_rays, const uint32_t *__restrict__ cand,
                                                    const uint32_t *__restrict__ cand_cnt, const Spill &sp,
@@ -1515,7 +1517,7 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
             for (int j = 0; j < CAND_BATCH; j++) {
                 if (k0 + j >= n) break;
                 double t;
-                if ((id[j] & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
+                if (ENV && (id[j] & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
                     int inside;
                     t = environment_t_rec(rec[j], e, &inside);
                 } else if (id[j] & CAND_SPHERE) {
@@ -1524,7 +1526,7 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
                     int outside; d3 ph; double u, v;
                     t = tri_t(s.tris[__double2hiint(rec[j].x)], e, &outside, &ph, &u, &v);
                     if (t == 0) { general = true; t = -1; }
-                } else if (__double2hiint(rec[j].x) == REC_QUADRIC) {
+                } else if (ENV && __double2hiint(rec[j].x) == REC_QUADRIC) {
                     int outside, branch;
                     t = quadric_t(s.quadrics[s.objects[__double2loint(rec[j].x)].tri_begin], e, &outside, &branch);
                 } else {
@@ -1536,25 +1538,22 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
         evaluated += n;
     }
     if (general) {
-        bt = nearest_occluder_general(s, e, brute, rid, n_rays, cand, cand_cnt, sp, &evaluated, &overflowed);
+        bt = nearest_occluder_general<ENV>(s, e, brute, rid, n_rays, cand, cand_cnt, sp, &evaluated, &overflowed);
         if (!brute && n <= CAND_CAP) evaluated -= n; // walked twice, counted once
     }
     return bt;
 }
 
 // The closest occluder of one ray (the same in every lane) over EVERY primitive, the lanes of the wave sharing
-// the list: what nearest_occluder's walk over everything returns, 64 primitives at a time.  Objects take
-// hits with t >= 0, triangles with t > 0 (a mesh reports its smallest t only if that is > 0); a triangle hit at
-// exactly t = 0 removes its whole mesh, which only the ordered walk knows how to do, so then every lane walks.
-__device__ __forceinline__ double wave_min_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ double nearest_occluder_wave(const SceneView &s, const Ray &e, uint32_t rid, uint32_t n_rays) {
+// the list: the primitive that nearest_occluder's walk over everything takes its distance from, found 64
+// primitives at a time; -1 when there is none.  Objects take hits with t >= 0, triangles with t > 0 (a mesh
+// reports its smallest t only if that is > 0); a triangle hit at exactly t = 0 removes its whole mesh, which only
+// the ordered walk knows how to do: -2 then.
+__device__ __forceinline__ int nearest_occluder_wave(const SceneView &s, const Ray &e) {
     const int lane = threadIdx.x & 63;
     const int first_env = s.n_planes + s.n_spheres, first_quadric = first_env + s.n_envs, first_tri = first_quadric + s.n_quadrics;
     double bt = RT_FLT_MAX;
+    int bprim = -1;
     bool zero_tri = false;
     for (int k = lane; k < s.n_prims; k += 64) {
         const int prim = s.kind_prims[k];
@@ -1574,14 +1573,16 @@ __device__ __forceinline__ double nearest_occluder_wave(const SceneView &s, cons
             int outside, branch;
             t = quadric_t(s.quadrics[s.objects[s.prim_obj[prim]].tri_begin], e, &outside, &branch);
         }
-        if (t >= 0 && t < bt) bt = t;
+        if (t >= 0 && t < bt) { bt = t; bprim = prim; }
     }
-    if (__any(zero_tri)) {
-        Spill none; none.pool = nullptr; none.count = nullptr;
-        uint32_t ev = 0, ov = 0;
-        return nearest_occluder(s, e, true, rid, n_rays, nullptr, nullptr, none, ev, ov);
+    if (__any(zero_tri)) return -2;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ot = __shfl_xor(bt, off, 64);
+        const int op = __shfl_xor(bprim, off, 64);
+        if (ot < bt || (ot == bt && op >= 0 && (bprim < 0 || op < bprim))) { bt = ot; bprim = op; }
     }
-    return wave_min_d(bt);
+    return bprim;
 }
 
 // the colour of grid point (x, y): a pixel of the frame, or a sub-sample kept for k_average
@@ -2433,12 +2434,12 @@ __global__ __launch_bounds__(256) void k_fold_levels(Frame f, Work w, unsigned c
 
 // The shadow rays of the hits far from the scene (bit 26 of their record, see FAR_SCALE) against everything.
 // One lane doing that alone in k_shade_group holds its wave for n_prims tests per light, so it is done here,
-// a wave taking one such hit at a time with its lanes sharing the primitive list; the distances wait in the
-// ray's first two candidate slots of each light.  Frames without such hits leave at the first line.
+// a wave taking one such hit at a time with its lanes sharing the primitive list; the closest occluder found
+// becomes the ray's whole candidate list for that light, which the shading kernel then walks as any other.
+// Frames without such hits leave at the first line.
 __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, Frame f, Work w, Group cur) {
     if (w.counters[15] == 0) return;
     const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_eval = 0;
     const bool far = rid < f.n_rays && w.rec_obj[rid] >= 0 && ((w.rec_cm0[rid] >> 25) & 3u) == 2u; // far, not emissive
     d3 fp = D3(0, 0, 0), fn = D3(0, 0, 0);
     if (far) {
@@ -2452,7 +2453,6 @@ __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, F
         todo &= todo - 1;
         const d3 p = D3(__shfl(fp.x, src, 64), __shfl(fp.y, src, 64), __shfl(fp.z, src, 64));
         const d3 nrm = D3(__shfl(fn.x, src, 64), __shfl(fn.y, src, 64), __shfl(fn.z, src, 64));
-        const uint32_t src_rid = (uint32_t)__shfl((int)rid, src, 64);
         for (int g = 0; g < cur.count; g++) {
             const DLight &L = sh.lights[cur.k0 + g];
             const d3 nhl = light_nhl(L, p);
@@ -2460,15 +2460,13 @@ __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, F
             Ray sr; // as shade_light builds it
             if (L.type == 0) { sr.pe = p; sr.npe = ld3(L.shadow_dir); }
             else sr = mkview(p, vmul(nhl, -1));
-            const double t = nearest_occluder_wave(s, sr, src_rid, f.n_rays);
-            if ((int)(threadIdx.x & 63) == src) {
-                uint32_t *slot = w.cand + (size_t)g * CAND_CAP * f.n_rays + rid;
-                slot[0] = (uint32_t)__double2loint(t); slot[f.n_rays] = (uint32_t)__double2hiint(t);
-                n_eval += (uint32_t)s.n_prims;
+            const int prim = nearest_occluder_wave(s, sr);
+            if ((int)(threadIdx.x & 63) == src) { // the list the shading kernel will walk: that primitive, nothing, or everything
+                w.cand_cnt[(size_t)g * f.n_rays + rid] = prim >= 0 ? 1u : (prim == -1 ? 0u : CAND_UNSEARCHED);
+                if (prim >= 0) w.cand[(size_t)g * CAND_CAP * f.n_rays + rid] = cand_id(s, prim);
             }
         }
     }
-    wave_count(w.counters, 1, n_eval);
 }
 
 // Shader::shading's loop over the lights (shader.h:60-94) for the lights of one group: colour before
@@ -2477,6 +2475,7 @@ __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, F
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4 // waves per SIMD the shading kernel's register budget allows
 #endif
+template <bool ENV> // the scene holds an Environment or a quadric (their tests are compiled out otherwise)
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView s, ShaderView sh, Frame f, Work w, Group cur,
                                                      Group next, unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2506,7 +2505,6 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     const uint32_t cm0w = w.rec_cm0[rid];
     h.cm0 = cm0w & 0xffffffu; h.cm1 = w.rec_cm1[rid];
     h.no_border = (cm0w >> 24) & 1u;
-    const bool far = (cm0w >> 26) & 1u; // its shadow rays were tested against everything by k_shade_far
     if ((cm0w >> 25) & 1u) { // an Environment: its colour as it is (shader.h:70-72)
         if (last) store_pixel(pixmap, f, w, rid, x, y, h.cm0);
         break;
@@ -2519,11 +2517,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
-            if (far) { // found above
-                const uint32_t *slot = w.cand + (size_t)g * CAND_CAP * n + rid;
-                return __hiloint2double((int)slot[n], (int)slot[0]);
-            }
-            return nearest_occluder(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+            return nearest_occluder<ENV>(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
                                     w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
         }, unused);
     }
@@ -3447,7 +3441,10 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
             if ((rc1 = clear_bins(next))) return rc1;
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
             hipLaunchKernelGGL(k_shade_far, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur);
-            hipLaunchKernelGGL(k_shade_group, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
+            if (sc->view.n_envs + sc->view.n_quadrics > 0)
+                hipLaunchKernelGGL(k_shade_group<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
+            else
+                hipLaunchKernelGGL(k_shade_group<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
             resolves++;
             cur = next;
