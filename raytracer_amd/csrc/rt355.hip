@@ -432,7 +432,8 @@ __device__ __forceinline__ float4 bundle_ray(const Bundle &bd, d3 ph, d3 nhl) {
     // ... and the reference's own rounding: from an origin far along the common direction (a mirror ray's hit on an
     // unbounded quadric or plane can lie 1e19 away) Sphere::CalcIntersect's B * B - C cancels to noise of
     // ~2e-8 |pe - c| in the distance it can tell from the radius, so spheres that far off the line may "hit"
-    double er = RT_EPS22 * (fabs(pu) + fabs(pv)) + 1.2e-7 * fabs(dot(ph, bd.dir));
+    // (|ph|_1 bounds the distance along the direction; the direction itself would cost the callers 48 more scalars)
+    double er = RT_EPS22 * (fabs(pu) + fabs(pv)) + 1.2e-7 * (fabs(ph.x) + fabs(ph.y) + fabs(ph.z));
     double msq = (2.0 * bd.rmaxp * er + er * er) * (1.0 + 1e-5);
     return make_float4((float)pu, (float)pv, (float)(msq * (1.0 + 1e-6)), (float)(4.0 * er));
 }
