@@ -646,6 +646,41 @@ def test_random_glass_in_a_room(api, oracle, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(60, 66))
+def test_random_scenes_with_textures(api, oracle, seed):
+    """The random scenes with texture mapping (type 1), solid textures with random projectors (type 2) and the
+    3D function (type 3) on a third of their objects -- planes, spheres, meshes -- some of them mirrors.  Bar: the
+    sphere mapping goes through acos, which the device and glibc may round differently in the last bit
+    (shader.h:213,222), so at most 0.1 % of the pixels may differ, by one unit; every other texture path is
+    integer arithmetic on the same doubles."""
+    sc, sh, cam, w, h = _random_case(seed)
+    rng = S.SplitMix64(7171 + seed)
+    n = B._normalize
+    for i, o in enumerate(sc.objects):
+        u = rng.uniform()
+        if u > 0.35:
+            continue
+        kind = 1 + int(rng.uniform(0, 3))
+        frame = None
+        if kind == 2:
+            frame = (n((1, rng.uniform(-0.3, 0.3), 0)), n((rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), 1)),
+                     n((rng.uniform(-0.2, 0.2), -1, rng.uniform(-0.3, 0.3))), (rng.uniform(-10, 10), rng.uniform(0, 20), rng.uniform(-5, 8)))
+        sx, sy = (rng.uniform(5, 40), rng.uniform(5, 40)) if kind == 2 else (rng.uniform(0.3, 6), rng.uniform(0.3, 6))
+        for k in range(2):
+            sc.add_texture(i, S._small_texture(8 + 8 * int(rng.uniform(0, 4)), 8 + 8 * int(rng.uniform(0, 3)), seed * 100 + 2 * i + k), sx, sy, frame=frame)
+        sc.set_texture_type(i, kind)
+        if rng.uniform() < 0.2:
+            o["ks"] = 0.5
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    r = api.Renderer(sc)
+    for mode in (B.MODE_PACKET, B.MODE_BRUTE):
+        got, st = r.render(cam, sh, w, h, mode=mode)
+        _compare(got, want, exact=bool(os.environ.get("RT355_TEST_EXACT")))  # (the sweep can ask for every byte)
+        assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"], mode
+    r.close()
+
+
+@pytest.mark.gpu
 def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
     """CalcSubPixel2 with shading3 / shading2 (main.cpp:163-209, shader.h:100-191), HEAD's renderer: frames
     the reference's own shader code produced (fixtures), then more cases against the CPU checker, ray counts
