@@ -681,6 +681,30 @@ def test_random_scenes_with_textures(api, oracle, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(70, 74))
+def test_random_scenes_gather(api, oracle, seed):
+    """HEAD's renderer (CalcSubPixel2 with shading3 / shading2, main.cpp:163-209) on the random scenes: 12 or 42
+    directions, both shaders, with and without supersampling; the gather rays of the searched modes go through
+    the scene table one direction per pass, those of BRUTE through the one-kernel walk."""
+    sc, sh, cam, w, h = _random_case(seed)
+    level = seed % 2
+    shading = (B.SHADING_BLEED, B.SHADING_OCCLUSION)[(seed // 2) % 2]
+    alias = (0, 2)[(seed // 4) % 2]
+    if alias:
+        w, h = w // 2, h // 2
+        cam = B.camera(tuple(cam.p_eye), tuple(cam.v_view), (0, 0, 1), 10.0, w, h)
+    dirs = B.geodesic(B.icosphere(level))
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=seed, shading=shading), threads=0, dirs=dirs)
+    r = api.Renderer(sc)
+    r.set_directions(dirs)
+    for mode in (B.MODE_PACKET, B.MODE_BRUTE):
+        got, st = r.render(cam, sh, w, h, alias=alias, seed=seed, shading=shading, mode=mode)
+        _compare(got, want)
+        assert st["gather_rays"] == wst["gather_rays"] > 0, mode
+    r.close()
+
+
+@pytest.mark.gpu
 def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
     """CalcSubPixel2 with shading3 / shading2 (main.cpp:163-209, shader.h:100-191), HEAD's renderer: frames
     the reference's own shader code produced (fixtures), then more cases against the CPU checker, ray counts

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """More seeds of the randomised GPU parity tests than the suite runs (GPU box):
     python tools/parity_sweep.py FIRST_SEED N_SEEDS [family ...]
-Every family is one of the six seed-parametrised tests of tests/test_gpu_parity.py, called with other seeds; a
+Every family is one of the seed-parametrised tests of tests/test_gpu_parity.py, called with other seeds; a
 failure is printed with its family and seed and the sweep goes on.  Progress goes to stdout line by line."""
 import os
 import sys
@@ -23,7 +23,7 @@ def main():
     import test_gpu_parity as T
     families = {"search": T.test_random_scenes_search_is_conservative, "mirrors": T.test_random_scenes_with_mirrors,
                 "environment": T.test_random_scenes_inside_an_environment, "quadrics": T.test_random_scenes_with_quadrics,
-                "glass": T.test_random_glass_in_a_room, "textures": T.test_random_scenes_with_textures}
+                "glass": T.test_random_glass_in_a_room, "textures": T.test_random_scenes_with_textures, "gather": T.test_random_scenes_gather}
     chosen = sys.argv[3:] or list(families)
     oracle = Oracle()
     failed = []
