@@ -284,6 +284,21 @@ def test_full_size_properties(api, oracle):
     r.close()
 
 
+@pytest.mark.parametrize("name", ["glass", "quadrics", "main_all", "environment", "solid_texture"])
+def test_full_size_every_object_class(api, oracle, name):
+    """The small cases that hold the other object classes, texture types and refraction, at the metric's 3840x2160:
+    whole frame and ray counts equal to the CPU checker's (these scenes are unsearched: one kernel per frame)."""
+    w, h = 3840, 2160
+    sc, sh, _, _, _ = S.small_case(name)
+    cam = S.default_camera(w, h)
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    r = api.Renderer(sc)
+    got, st = r.render(cam, sh, w, h)
+    r.close()
+    _compare(got, want, exact=(name != "environment"))  # (its sphere mapping goes through acos: <= 0.1 % pixels, 1 unit)
+    assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"]
+
+
 def test_full_size_gather(api, oracle):
     """The renderer HEAD of the reference selects, at the metric's size: the default scene at 3840x2160 under
     shading3 with 42 gather directions (350 M rays), whole-frame hash and ray count equal to the CPU checker's;
