@@ -1,22 +1,29 @@
 #!/usr/bin/env python
 """Benchmark of the accelerated render path: Mrays/s (primary + shadow) at 3840x2160.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shard frames|slabs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shard frames|slabs|tiles]
                     [--mode packet|allpairs]
 
-The headline workload is the default scene at 3840x2160 (`default_4k`).  At N = 1 the two
-throughput scenes (`spheres10k_8lights_4k`, `mesh100k_2lights_4k`) and the default scene under the
-renderer HEAD of the reference selects (`default_bleed162_4k`: CalcSubPixel2 with shading3 on 162 gather
-directions) are measured the same way after it and reported under "other_configs" of the same JSON line.  Searched scenes use the library's
-default search (packet: beams against a direction-sorted table); the all-pairs search (every ray x
-every primitive in fp32, the FP32-VALU-bound kernel) is timed beside it and reported in
-"all_pairs" with its own roofline.
+The headline workload is the default scene at 3840x2160 (`default_4k`).  At N = 1 the throughput scenes
+(`spheres10k_8lights_4k`, `mesh100k_2lights_4k`, the 60-camera sweep `mesh100k_sweep60`), the default scene
+under the renderer HEAD of the reference selects (`default_bleed162_4k`: CalcSubPixel2 with shading3 on 162
+gather directions), the mirror scene and the glass room are measured the same way after it and reported
+under "other_configs" of the same JSON line.  Searched scenes use the library's default search (packet:
+beams against a direction-sorted table); the all-pairs search (every ray x every primitive in fp32, the
+FP32-VALU-bound kernel) is timed beside it and reported in "all_pairs" with its own roofline.
 
-One step = one frame of the workload rendered by rt355_render_device into a framebuffer that
-stays in HBM (scene, tables and framebuffer are all device-resident when the timed region
-starts).  N > 1 is launched by torch.distributed.run, one rank per GPU; ranks render whole
-frames independently (weak scaling, no data-path collective) or, with --shard slabs, row slabs
-of one frame followed by the final-frame gather over RCCL.
+One step = one frame of the workload rendered by rt355_render -- the call that stands where the reference has
+setPixels (main.cpp:339-376,640) -- into a page-locked host pixmap: the scene and its tables are resident in
+HBM when the timed region starts, and the readback of the frame is inside it (`value`).  The same frames
+rendered by rt355_render_device with the framebuffer left in HBM are timed beside it
+(`value_device_resident`).  A sweep workload's step is its whole camera sweep.
+
+N > 1: one rank per GPU, launched by torch.distributed.run or, when WORLD_SIZE is not set, spawned by this
+script itself before it touches the GPU.  Ranks render whole frames independently (--shard frames: weak
+scaling, no data-path collective; a sweep deals its frames round robin, frame f on rank f mod N, a fixed
+total) or one frame between them (--shard slabs: contiguous row slabs; --shard tiles: interleaved 32-row
+tiles; a fixed total), followed by the only exchange of the path: the gather of the final frame over RCCL
+and its readback on rank 0.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,6 +32,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,6 +49,7 @@ ALGO_FLOPS = {"sphere": 18.0, "plane": 14.0, "tri_front": 50.0, "tri_culled": 13
 # flops the search kernel EXECUTES per pair: 3 FMA (6) + its share of the max-fold (8 max3 per
 # 16 pairs, 2 compares each = 1) + 1/16 of the group compare
 EXEC_FLOPS_PER_PAIR = 6.0 + 1.0 + 1.0 / 16.0
+TRAFFIC_FILE = "r2_traffic.json"
 
 
 def build_workload(name: str):
@@ -73,13 +82,34 @@ def build_workload(name: str):
         w, h = 3840, 2160
         sc, sh, _, _, _ = S.small_case("glass")
         return sc, sh, S.default_camera(w, h), w, h
-    if name == "mesh1m_2lights_8k":
+    if name in ("mesh1m_2lights_8k", "mesh1m_8k_tiles", "mesh1m_8k_slabs"):
+        # the 1 M-triangle scene at 7680x4320; _tiles / _slabs: one frame shared between the ranks
         w, h = 7680, 4320
         return S.mesh_scene(1_000_000, seed=356), S.mesh_shader(), S.default_camera(w, h), w, h
+    if name == "mesh100k_sweep60":  # 60 cameras orbiting the triangle scene; one step = the whole sweep
+        w, h = 3840, 2160
+        return S.mesh_scene(100_000, seed=356), S.mesh_shader(), S.orbit_camera(0, w, h), w, h
+    if name == "mesh4k_sweep6_small":  # quick functional run of the sweep
+        w, h = 320, 180
+        return S.mesh_scene(4000, seed=356, tex_size=64), S.mesh_shader(), S.orbit_camera(0, w, h), w, h
     if name == "spheres1k_2lights_small":  # quick functional run
         w, h = 640, 360
         return S.spheres_scene(1000, seed=355), S.spheres_shader(2), S.default_camera(w, h), w, h
     raise SystemExit(f"unknown workload {name}")
+
+
+def sweep_of(name: str, w: int, h: int):
+    """The cameras of a sweep workload (one step renders all of them), or None."""
+    from raytracer_amd import scenes as S
+    if name == "mesh100k_sweep60":
+        return [S.orbit_camera(f, w, h, n_frames=60) for f in range(60)]
+    if name == "mesh4k_sweep6_small":
+        return [S.orbit_camera(10 * f, w, h, n_frames=60) for f in range(6)]
+    return None
+
+
+# the partition a workload is meant for when --shard is left at its default
+DEFAULT_SHARD = {"mesh1m_8k_tiles": "tiles", "mesh1m_8k_slabs": "slabs"}
 
 
 def gather_of(name: str):
@@ -88,7 +118,7 @@ def gather_of(name: str):
     from raytracer_amd import binding as B
     if name == "default_bleed162_4k":
         return B.SHADING_BLEED, B.geodesic(B.icosphere(2))
-    if name == "mesh100k_bleed42_4k":  # a searched scene: the gather rays go through the scene table, one direction per pass
+    if name == "mesh100k_bleed42_4k":  # a searched scene: the gather rays go through the scene table
         return B.SHADING_BLEED, B.geodesic(B.icosphere(1))
     return B.SHADING_LIGHTS, None
 
@@ -123,29 +153,41 @@ def algorithmic_flops(scene, shader, cam, stats) -> float:
     return stats["primary_rays"] * per_ray_primary + sum(shadow_per_light * f for f in per_ray_shadow) + gather
 
 
-def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None):
+def count_rays(q) -> float:
+    return float(q["primary_rays"] + q["shadow_rays"] + q["gather_rays"] + q["secondary_rays"])
+
+
+def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None, gpu_frame=None):
     """The CPU checker (oracle/rt_oracle.c, a port of the reference path) timed on a strided pixel sample of
     the same frame, all `threads` cores and one; and, where the harness around the reference's own classes was
-    built (oracle/_ref), that code on a few rows of the same frame, one thread as the reference runs."""
+    built (oracle/_ref), that code on a few rows of the same frame, one thread as the reference runs.  The
+    sample's pixels must equal the frame the GPU rendered in the timed region (gpu_frame), byte for byte."""
     from oracle.oracle_py import Oracle, Reference
     from raytracer_amd import binding as B
     O = Oracle()
     p = scene.pack()
     t0 = time.perf_counter()
-    _, st = O.render(p, cam, shader, B.opts(w, h, shading=shading), threads=threads, stride=stride, dirs=dirs)
+    sample, st = O.render(p, cam, shader, B.opts(w, h, shading=shading), threads=threads, stride=stride, dirs=dirs)
     dt = time.perf_counter() - t0
-    count = lambda q: q["primary_rays"] + q["shadow_rays"] + q["gather_rays"] + q["secondary_rays"]
-    rays = count(st)
-    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    parity = "not checked"
+    if gpu_frame is not None:
+        a, b = sample[::stride, ::stride], gpu_frame[::stride, ::stride]
+        ndiff = int((a != b).any(axis=2).sum())
+        if ndiff:
+            raise SystemExit(f"parity: {ndiff} of the {a.shape[0] * a.shape[1]} pixels the CPU checker sampled differ from the GPU frame")
+        parity = "ok"
+    out = {"value": count_rays(st) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "parity_sample": parity,
            "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
                      f"{st['shadow_rays']} shadow + {st['gather_rays']} gather + {st['secondary_rays']} mirror or refracted rays, {dt:.2f} s)"}
     # one thread of the same port, on a sample a thread finishes in seconds
     s1 = stride * (4 if scene.n_primitives >= 1000 else 1)
-    t0 = time.perf_counter()
-    _, st1 = O.render(p, cam, shader, B.opts(w, h, shading=shading), threads=1, stride=s1, dirs=dirs)
-    dt1 = time.perf_counter() - t0
-    out["one_thread"] = {"value": count(st1) / dt1 / 1e6, "unit": "Mrays/s",
-                         "sample": f"every {s1}th pixel in x and y ({dt1:.2f} s)"}
+    if scene.n_primitives < 500_000:  # (a thread needs minutes for any sample of a larger scene)
+        t0 = time.perf_counter()
+        _, st1 = O.render(p, cam, shader, B.opts(w, h, shading=shading), threads=1, stride=s1, dirs=dirs)
+        dt1 = time.perf_counter() - t0
+        out["one_thread"] = {"value": count_rays(st1) / dt1 / 1e6, "unit": "Mrays/s",
+                             "sample": f"every {s1}th pixel in x and y ({dt1:.2f} s)"}
     # the reference's own classes (CalcIntersect, Shader::shading, Color ...) driven by the harness, one thread
     work = scene.n_primitives * (1 + len(shader.lights))
     rows = 64 if work < 200 else (1 if work < 200_000 else 0)
@@ -159,7 +201,7 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None
         R.render(p, cam, shader, o, dirs=dirs)
         dtr = time.perf_counter() - t0
         out["reference_classes_one_thread"] = {
-            "value": count(sts) / dtr / 1e6, "unit": "Mrays/s", "kind": "reference",
+            "value": count_rays(sts) / dtr / 1e6, "unit": "Mrays/s", "kind": "reference",
             "sample": f"rows {h // 2}..{h // 2 + rows - 1} of the same frame ({sts['primary_rays']} primary + "
                       f"{sts['shadow_rays']} shadow + {sts['gather_rays']} gather + {sts['secondary_rays']} mirror or refracted rays, {dtr:.2f} s); the harness "
                       f"compiles the reference's headers, main.cpp itself needs GLUT"}
@@ -193,25 +235,23 @@ def measured_traffic(workload, kernel):
     and --pmc WRITE_SIZE, separate passes of this same bench command: tools/traffic_passes.sh), read from the
     committed summary; FETCH_SIZE doubled, as gfx950 tallies a 128-byte request as 64 bytes.  None when the
     summary does not hold the pair."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     try:
         rec = json.load(open(path))[workload][kernel]
     except (OSError, KeyError, ValueError):
         return None
     return {"bytes": (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0, "fetch_kib_counter": rec["fetch_kb"],
-            "write_kib_counter": rec["write_kb"], "source": "profiles/r1_traffic.json"}
+            "write_kib_counter": rec["write_kb"], "source": "profiles/" + TRAFFIC_FILE}
 
 
-def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None, detail=False):
-    """`steps` frames back to back, each synchronised before the next is enqueued.  With detail=True the
-    HIP-event kernel times of every frame are read back and summed (not done inside timed regions)."""
+def run_frames(r, cam, shader, o, fb, stream, steps, detail=False):
+    """`steps` frames by rt355_render_device, the framebuffer left in HBM, each synchronised before the next is
+    enqueued.  With detail=True the HIP-event kernel times of every frame are read back and summed."""
     acc = {"search_ms": 0.0, "search_launches": 0, "resolve_ms": 0.0, "resolve_launches": 0, "pairs": 0,
            "primary_ms": 0.0, "shade_ms": 0.0, "shade_launches": 0, "frames": steps}
     stats = None
     for _ in range(steps):
         r.render_device(cam, shader, o, fb.data_ptr(), stream)
-        if extra_step:
-            extra_step()
         stats = r.sync()
         if detail:
             ms, n = r.search_kernel_ms()
@@ -224,42 +264,75 @@ def run_frames(r, cam, shader, o, fb, stream, steps, extra_step=None, detail=Fal
     return acc, stats
 
 
-def measure(name, args, ctx, headline):
-    """One workload: W warm-up frames, K timed frames between barriers (max over ranks), then, on rank 0 and
-    outside the timed region, kernel-time breakdown, rooflines, the all-pairs comparison and the CPU baseline."""
+def measure(name, args, ctx):
+    """One workload: W warm-up steps, K timed steps between barriers (max over ranks), then, on rank 0 and
+    outside the timed region, the device-resident figure, kernel-time breakdown, rooflines, the all-pairs
+    comparison and the CPU baseline."""
     import torch
     from raytracer_amd import binding as B
-    from raytracer_amd.api import Renderer
-    from raytracer_amd.sharding import gather_frame, slab_rows
+    from raytracer_amd.api import HostPixmap, Renderer
+    from raytracer_amd.sharding import frames_for_rank, gather_frame, rows_of, TILE_ROWS
     dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
 
     scene, shader, cam, w, h = build_workload(name)
     shading, dirs = gather_of(name)
+    cams = sweep_of(name, w, h)
+    shard = args.shard or DEFAULT_SHARD.get(name, "frames")
+    split = world > 1 and shard in ("slabs", "tiles") and cams is None  # one frame between the ranks
     r = Renderer(scene)
     if dirs is not None:
         r.set_directions(dirs)
-    fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     mode = B.MODE_PACKET if args.mode == "packet" else B.MODE_ALLPAIRS
-    if args.shard == "slabs" and world > 1:
-        b, e = slab_rows(h, world)[rank]
-        o = B.opts(w, h, row_begin=b, row_end=e, mode=mode, shading=shading)
-    else:
-        o = B.opts(w, h, mode=mode, shading=shading)
+    o = B.opts(w, h, mode=mode, shading=shading)
     stream = torch.cuda.current_stream().cuda_stream
-    gather = (lambda: gather_frame(fb, rank, world, dst=0)) if (args.shard == "slabs" and world > 1) else None
+    host = HostPixmap(w, h)  # page-locked, in place of `new unsigned char[width * height * 3]` (main.cpp:544)
+    fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+
+    if split:
+        if shard == "tiles":
+            o_part = B.opts(w, h, mode=mode, shading=shading, tile_rows=TILE_ROWS, tile_count=world, tile_phase=rank)
+        else:
+            b, e = rows_of(h, world, rank, "slabs")[0]
+            o_part = B.opts(w, h, row_begin=b, row_end=e, mode=mode, shading=shading)
+        host_t = torch.from_numpy(host.array)
+
+        def step():
+            # this rank's rows into its framebuffer in HBM, the final frame gathered on rank 0 (RCCL), read back there
+            r.render_device(cam, shader, o_part, fb.data_ptr(), stream)
+            st = r.sync()
+            full = gather_frame(fb, rank, world, dst=0, shard=shard)
+            if rank == 0:
+                host_t.copy_(full)
+            return count_rays(st), st
+    elif cams is not None:
+        mine = frames_for_rank(len(cams), rank, world) if world > 1 else list(range(len(cams)))
+
+        def step():
+            rays, st = 0.0, None
+            for f in mine:  # frame f on rank f mod N; every frame moves the camera (the eye's tables are rebuilt)
+                _, st = r.render(cams[f], shader, w, h, mode=mode, shading=shading, out=host.array)
+                rays += count_rays(st)
+            return rays, st
+    else:
+        def step():
+            _, st = r.render(cam, shader, w, h, mode=mode, shading=shading, out=host.array)
+            return count_rays(st), st
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_frames(r, cam, shader, o, fb, stream, args.warmup, gather)
+    for _ in range(args.warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
-    _, stats = run_frames(r, cam, shader, o, fb, stream, args.steps, gather)
+    rays_step, stats = 0.0, None
+    for _ in range(args.steps):
+        rays_step, st_ = step()
+        stats = st_ or stats
     barrier()
     dt = time.perf_counter() - t0
-    rays_step = float(stats["primary_rays"] + stats["shadow_rays"] + stats["gather_rays"] + stats["secondary_rays"])
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -269,6 +342,7 @@ def measure(name, args, ctx, headline):
         rays_step = float(rays_all.item())
     if rank != 0:
         r.close()
+        host.close()
         return None
 
     def valu_roofline(acc, stats):
@@ -288,20 +362,46 @@ def measure(name, args, ctx, headline):
 
     ms_per_step = dt * 1e3 / args.steps
     value = rays_step * args.steps / dt / 1e6
-    n_rays_padded = ((w + 31) // 32) * (((o.row_end or h) - o.row_begin + 31) // 32) * 1024
+    gpu_frame = host.array.copy()  # the last frame of the timed region, as the caller of rt355_render received it
+    fixed_total = split or (cams is not None and world > 1)
     out = {"value": round(value, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4),
+           "timed": ("rt355_render_device of this rank's rows + gather of the final frame on rank 0 + its readback" if split else
+                     "rt355_render into a page-locked host pixmap (readback of the frame included)"),
+           "scaling": "strong" if fixed_total else "weak",
            "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives,
-                      "lights": len(shader.lights), "alias": 0, "shard": args.shard, "search": args.mode,
+                      "lights": len(shader.lights), "alias": 0, "shard": shard if (world > 1 or cams is None) else "frames",
+                      "frames_per_step": len(cams) if cams is not None else 1, "search": args.mode,
                       "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"],
                                          "gather": stats["gather_rays"], "mirror": stats["secondary_rays"]},
                       "shading": {0: "Shader::shading", 1: "Shader::shading2", 2: "Shader::shading3"}[shading],
                       "gather_directions": 0 if dirs is None else len(dirs),
                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
                       "packet_survivors": stats["packet_survivors"]}}
+    if world > 1:  # the breakdowns below describe one GPU rendering whole frames
+        r.close()
+        host.close()
+        return out
+    # ---- the same frames with the framebuffer left in HBM (no readback)
+    dev_cams = cams if cams is not None else [cam]
+    for c in dev_cams[:2]:
+        run_frames(r, c, shader, o, fb, stream, 1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    rays_dev, stats = 0.0, None
+    for _ in range(args.steps):
+        for c in dev_cams:
+            _, stats = run_frames(r, c, shader, o, fb, stream, 1)
+            rays_dev += count_rays(stats)
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t1
+    out["value_device_resident"] = round(rays_dev / dt1 / 1e6, 2)
+    out["ms_per_step_device_resident"] = round(dt1 * 1e3 / args.steps, 4)
+    assert np.array_equal(fb.cpu().numpy(), gpu_frame), "rt355_render and rt355_render_device gave different frames"
+    n_rays_padded = ((w + 31) // 32) * ((h + 31) // 32) * 1024
     # ---- kernel-time breakdown: a few more frames, HIP-event times read back after each
     K = 3
-    acc, stats = run_frames(r, cam, shader, o, fb, stream, K, None, detail=True)  # rank 0 alone: no gather here
+    acc, stats = run_frames(r, dev_cams[-1], shader, o, fb, stream, K, detail=True)
     searched = acc["search_launches"] > 0
     nl = len(shader.lights)
     out["kernel_time"] = {"search_ms_per_frame": round(acc["search_ms"] / K, 4),
@@ -356,39 +456,77 @@ def measure(name, args, ctx, headline):
         dominant = max(rooflines, key=lambda k: times[k])
         out["roofline"] = rooflines[dominant]
         out["roofline_other_kernels"] = {k: v for k, v in rooflines.items() if k != dominant}
+    traffic_name = {"mesh100k_sweep60": "mesh100k_2lights_4k"}.get(name, name)
     for rf in [out["roofline"], *out.get("roofline_other_kernels", {}).values()]:
-        t = measured_traffic(name, rf["kernel"]) if (args.mode == "packet" and rf.get("frac") is not None) else None
+        t = measured_traffic(traffic_name, rf["kernel"]) if (args.mode == "packet" and rf.get("frac") is not None) else None
         if t:
             rf["traffic"] = t["bytes"]
             rf["traffic_detail"] = t
-    if world == 1 and args.mode == "packet" and not args.no_allpairs and searched:
-        o2 = B.opts(w, h, mode=B.MODE_ALLPAIRS)
+    if args.mode == "packet" and not args.no_allpairs and searched and cams is None and scene.n_primitives < 500_000:
+        o2 = B.opts(w, h, mode=B.MODE_ALLPAIRS, shading=shading)
         run_frames(r, cam, shader, o2, fb, stream, 1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         acc2, stats2 = run_frames(r, cam, shader, o2, fb, stream, 3, detail=True)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
-        out["all_pairs"] = {"value": round(rays_step * 3 / dt2 / 1e6, 2), "unit": "Mrays/s", "steps": 3,
+        assert np.array_equal(fb.cpu().numpy(), gpu_frame), "the all-pairs search gave a different frame"
+        out["all_pairs"] = {"value_device_resident": round(count_rays(stats2) * 3 / dt2 / 1e6, 2), "unit": "Mrays/s", "steps": 3,
                             "ms_per_step": round(dt2 * 1e3 / 3, 4),
                             "search_ms_per_frame": round(acc2["search_ms"] / 3, 4),
                             "roofline": valu_roofline(acc2, stats2)}
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         stride = args.cpu_stride
         if stride == 0:
             work = scene.n_primitives * (1 + len(shader.lights))
-            stride = 1 if work < 200 else (4 if work < 5000 else 16)
+            stride = 1 if work < 200 else (4 if work < 5000 else (16 if work < 1_000_000 else 64))
         if shading:
             stride = 4
-        out["cpu_baseline"] = cpu_baseline(scene, shader, cam, w, h, stride, threads, shading, dirs)
+        out["cpu_baseline"] = cpu_baseline(scene, shader, dev_cams[-1], w, h, stride, threads, shading, dirs, gpu_frame)
     r.close()
+    host.close()
     return out
 
 
 HEADLINE = "default_4k"
-OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "default_bleed162_4k", "spheres10k_mirrors_8lights_4k",
-          "glass_room_4k"]
+OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "mesh100k_sweep60", "default_bleed162_4k",
+          "spheres10k_mirrors_8lights_4k", "glass_room_4k"]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` started by hand: one child process per rank with the environment
+    torch.distributed.run would give it.  The parent never touches the GPU; rank 0 prints the JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def check_launch(args) -> int:
+    """The N-rank start-up alone: every rank joins a gloo group from the environment it was given, the ranks
+    are summed, rank 0 prints one line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    seen = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.all_reduce(seen)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch": "ok", "n_gpus": world, "rank_sum": float(seen.item())}), flush=True)
+    return 0
 
 
 def main():
@@ -397,7 +535,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=HEADLINE)
-    ap.add_argument("--shard", choices=["frames", "slabs"], default="frames")
+    ap.add_argument("--shard", choices=["frames", "slabs", "tiles"], default=None,
+                    help="N > 1: whole frames per rank (default), or one frame in row slabs / interleaved 32-row tiles")
     ap.add_argument("--mode", choices=["packet", "allpairs"], default="packet",
                     help="search of searched scenes: packet = beams against a direction-sorted table "
                          "(library default); allpairs = fp32 test of every ray/primitive pair")
@@ -406,7 +545,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--check-launch", action="store_true",
+                    help="start the ranks, meet over gloo, print {\"launch\": \"ok\", ...} and stop: no GPU is touched")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # (before anything in this process touches the GPU)
+    if args.check_launch:
+        sys.exit(check_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -414,8 +560,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     # rehearsal of the N > 1 path on a one-GPU box: every rank on device 0, collectives over gloo (RCCL refuses
     # two ranks on one device)
@@ -431,19 +577,20 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = {"dist": dist, "world": world, "rank": rank, "reduce_device": "cpu" if share else "cuda"}
 
-    head = measure(args.workload, args, ctx, headline=True)
+    head = measure(args.workload, args, ctx)
     others = {}
     if world == 1 and args.workload == HEADLINE and not args.no_others:
         for name in OTHERS:
-            others[name] = measure(name, args, ctx, headline=False)
+            others[name] = measure(name, args, ctx)
     if rank == 0:
         # (a workload that casts gather rays counts them too)
         out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-               "higher_is_better": True, "scaling": "weak" if (args.shard == "frames" or world == 1) else "strong",
-               "vs_baseline": None, "dtype": "f64" if head["kernel_time"]["search_ms_per_frame"] == 0 else "f32 search + f64 resolve",
+               "higher_is_better": True, "scaling": head["scaling"],
+               "vs_baseline": None, "dtype": "f64" if head["config"]["primitives"] < 64 else "f32 search + f64 resolve",
                "data": "synthetic"}
-        for k in ("config", "kernel_time", "roofline", "roofline_other_kernels", "all_pairs", "cpu_baseline"):
+        for k in ("timed", "value_device_resident", "ms_per_step_device_resident", "config", "kernel_time", "roofline",
+                  "roofline_other_kernels", "all_pairs", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]
         if others:

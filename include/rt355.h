@@ -154,6 +154,14 @@ typedef struct rt355_opts {
     int32_t mode;          /* RT355_MODE_*                                                  */
     uint32_t seed;         /* seed of the jitter (alias > 0) and of the gather rotation     */
     int32_t shading;       /* RT355_SHADING_*                                               */
+    /* Interleaved row tiles, the partition for frames whose cost is uneven from top to bottom (sky above,
+     * geometry below): the slab [row_begin,row_end) is cut into tiles of tile_rows rows (the last may be
+     * shorter), tile k belongs to share k % tile_count, and the call renders the tiles of share tile_phase
+     * only, in place (the other rows of the pixmap are not touched).  tile_count <= 1: the whole slab. */
+    int32_t tile_rows;     /* rows per tile (> 0 when tile_count > 1)                        */
+    int32_t tile_count;    /* number of shares the tiles are dealt to                       */
+    int32_t tile_phase;    /* the share this call renders, 0 <= tile_phase < tile_count      */
+    int32_t pad_;
 } rt355_opts;
 
 /* The jitter of CalcPixel.  The reference draws `(double)rand() / RAND_MAX` twice per sub-sample
@@ -232,6 +240,13 @@ int rt355_render(rt355_scene *scene, const rt355_camera *cam, const rt355_shader
 int rt355_render_device(rt355_scene *scene, const rt355_camera *cam,
                         const rt355_shader *shader, const rt355_opts *opts,
                         void *d_pixmap, void *hip_stream, rt355_stats *stats);
+
+/* Page-locked host memory for the pixmap handed to rt355_render (in place of `new unsigned char[...]`,
+ * main.cpp:544): the readback is then one DMA transfer straight into the caller's buffer.  rt355_render
+ * accepts any host pointer; one that is not page-locked is filled through a staging buffer at the cost
+ * of a host copy.  No counterpart in the reference. */
+void *rt355_host_alloc(uint64_t bytes);
+void rt355_host_free(void *p);
 
 /* Wait for the scene's outstanding render and fill the stats passed to it. */
 int rt355_scene_sync(rt355_scene *scene);

@@ -712,7 +712,8 @@ static int oscene_init(oscene *s, const rt355_scene_desc *d) {
  * Shader::shading does not use them (shader.h:90-91 calls CalcShadow).
  * `stride` > 1 renders only pixels with x % stride == 0 and y % stride == 0 (the rays
  * are the same as the full frame's; other pixels are left untouched) -- used to time a
- * bounded sample.  n_threads <= 0 = all cores; rows are interleaved over threads. */
+ * bounded sample.  n_threads <= 0 = all cores; rows are interleaved over threads.  With opts->tile_count > 1
+ * only the rows of the call's share of the row tiles are rendered (the multi-GPU partition, rt355.h). */
 int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const rt355_shader *sh,
                             const rt355_opts *opts, const double *dirs, int n_dirs, unsigned char *pixmap,
                             rt355_stats *stats, int n_threads, int stride);
@@ -745,6 +746,8 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : prim, shad, sec, gat, deep)
     for (int j = 0; j < n_sampled; j++) {
         const int y = y_first + j * stride;
+        /* interleaved row tiles (rt355_opts.tile_*): only the rows of this call's share */
+        if (opts->tile_count > 1 && opts->tile_rows > 0 && ((y - y0) / opts->tile_rows) % opts->tile_count != opts->tile_phase) continue;
         octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0; cx.secondary_rays = 0;
         cx.dirs = dirs; cx.n_dirs = n_dirs; cx.gather_rays = 0; cx.too_deep = 0;
         const int alias = opts->alias;

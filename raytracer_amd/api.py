@@ -42,6 +42,10 @@ def lib():
         L.rt355_scene_destroy.restype = None
         L.rt355_render.argtypes = [C.c_void_p] * 6
         L.rt355_render_device.argtypes = [C.c_void_p] * 7
+        L.rt355_host_alloc.restype = C.c_void_p
+        L.rt355_host_alloc.argtypes = [C.c_uint64]
+        L.rt355_host_free.restype = None
+        L.rt355_host_free.argtypes = [C.c_void_p]
         L.rt355_scene_sync.argtypes = [C.c_void_p]
         L.rt355_scene_search_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.rt355_scene_resolve_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -82,9 +86,10 @@ class Renderer:
             pass
 
     def render(self, cam, shader: Shader, width: int, height: int, alias=0, row_begin=0, row_end=0,
-               mode=MODE_PACKET, out: np.ndarray | None = None, seed=0, shading=SHADING_LIGHTS):
+               mode=MODE_PACKET, out: np.ndarray | None = None, seed=0, shading=SHADING_LIGHTS,
+               tile_rows=0, tile_count=0, tile_phase=0):
         """Host framebuffer path (rt355_render).  Returns (pixmap (H,W,3) uint8, stats dict)."""
-        o = make_opts(width, height, alias, row_begin, row_end, mode, seed, shading)
+        o = make_opts(width, height, alias, row_begin, row_end, mode, seed, shading, tile_rows, tile_count, tile_phase)
         if out is None:
             out = np.zeros((height, width, 3), dtype=np.uint8)
         st = CStats()
@@ -144,6 +149,31 @@ class Renderer:
         _check(lib().rt355_probe_intersect(self.handle, obj, rays.ctypes.data, len(rays), out.ctypes.data),
                "rt355_probe_intersect")
         return out
+
+
+class HostPixmap:
+    """A page-locked pixmap (rt355_host_alloc) as a (height, width, 3) uint8 array: the readback of rt355_render
+    is then one DMA transfer into it.  Stands where the reference has `new unsigned char[width * height * 3]`
+    (main.cpp:544)."""
+
+    def __init__(self, width: int, height: int):
+        n = width * height * 3
+        self.ptr = lib().rt355_host_alloc(n)
+        if not self.ptr:
+            raise Rt355Error("rt355_host_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(self.ptr)).reshape(height, width, 3)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib().rt355_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def sincos(x: float):

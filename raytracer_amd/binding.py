@@ -71,7 +71,8 @@ class CShader(C.Structure):
 class COpts(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("alias", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("mode", C.c_int32),
-                ("seed", C.c_uint32), ("shading", C.c_int32)]
+                ("seed", C.c_uint32), ("shading", C.c_int32),
+                ("tile_rows", C.c_int32), ("tile_count", C.c_int32), ("tile_phase", C.c_int32), ("pad_", C.c_int32)]
 
 
 class CStats(C.Structure):
@@ -85,7 +86,7 @@ class CStats(C.Structure):
 
 
 assert C.sizeof(CTexture) == 128 and C.sizeof(CSceneDesc) == 48 and C.sizeof(CCamera) == 96
-assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 32 and C.sizeof(CStats) == 80
+assert C.sizeof(CShader) == 24 and C.sizeof(COpts) == 48 and C.sizeof(CStats) == 80
 
 
 def _normalize(v: Sequence[float]):
@@ -280,8 +281,11 @@ def camera(p_eye=(0, -20, 0), v_view=(0, 1, 0), v_up=(0, 0, 1), dist=10.0, width
     return c
 
 
-def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_PACKET, seed=0, shading=SHADING_LIGHTS) -> COpts:
-    return COpts(width, height, alias, row_begin, row_end, mode, seed, shading)
+def opts(width, height, alias=0, row_begin=0, row_end=0, mode=MODE_PACKET, seed=0, shading=SHADING_LIGHTS,
+         tile_rows=0, tile_count=0, tile_phase=0) -> COpts:
+    """rt355_opts.  tile_*: the interleaved row tiles of the multi-GPU partition (tile k of the slab belongs to
+    share k % tile_count; the call renders share tile_phase)."""
+    return COpts(width, height, alias, row_begin, row_end, mode, seed, shading, tile_rows, tile_count, tile_phase, 0)
 
 
 _M64 = 0xFFFFFFFFFFFFFFFF

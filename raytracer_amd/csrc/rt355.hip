@@ -39,7 +39,7 @@
 #include "../../include/rt355.h"
 #include "rt_exact.h"
 
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 #define SEARCH_THREADS 256
 #ifndef RAYS_PER_THREAD
 #define RAYS_PER_THREAD 4   // rays per lane of the search kernel (2, 4 or 8)
@@ -128,7 +128,16 @@ struct Frame {
     // Reflection on searched scenes renders a frame level by level (camera rays, their mirror rays, ...): the
     // shading of level `level` >= 0 goes to Work::lvl_clr and k_fold writes the pixels; -1 = no levels.
     int32_t level;
+    // Interleaved row tiles (the multi-GPU partition for frames whose cost is uneven from top to bottom): the slab
+    // is cut into tiles of tile_rows rows and this call renders tiles tile_phase, tile_phase + tile_count, ...;
+    // `rows` then counts the rows of those tiles only.  tile_count <= 1: the slab as a whole.
+    int32_t tile_rows, tile_count, tile_phase;
 };
+// row of the frame that local row `y` of the call is (local rows are the rows rendered, in order)
+__device__ __forceinline__ int frame_row(const Frame &f, int y) {
+    if (f.tile_count <= 1) return y + f.row_begin;
+    return f.row_begin + ((y / f.tile_rows) * f.tile_count + f.tile_phase) * f.tile_rows + y % f.tile_rows;
+}
 // inverse of rid_to_xy
 __device__ __forceinline__ uint32_t xy_to_rid(int x, int y, int tiles_x) {
     const uint32_t tile = (uint32_t)(y / TILE_H) * (uint32_t)tiles_x + (uint32_t)(x / TILE_W);
@@ -443,8 +452,8 @@ __device__ __forceinline__ float4 bundle_ray(const Bundle &bd, d3 ph, d3 nhl) {
 // (main.cpp:292-303)
 __device__ __forceinline__ Ray grid_ray(const DCamera &cam, const Frame &f, int gx, int gy) {
     if (f.alias <= 0)
-        return calc_view(cam, (double)gx / (double)f.width, (double)(gy + f.row_begin) / (double)f.height);
-    const int x = gx / f.alias, p = gx % f.alias, y = gy / f.alias + f.row_begin, q = gy % f.alias;
+        return calc_view(cam, (double)gx / (double)f.width, (double)frame_row(f, gy) / (double)f.height);
+    const int x = gx / f.alias, p = gx % f.alias, y = frame_row(f, gy / f.alias), q = gy % f.alias;
     const double pointX = (rt355x_jitter(f.seed, x, y, q * f.alias + p, 0) + p) / f.alias + x;
     const double pointY = (rt355x_jitter(f.seed, x, y, q * f.alias + p, 1) + q) / f.alias + y;
     return calc_view(cam, pointX / (double)f.width, pointY / (double)f.height);
@@ -1591,7 +1600,7 @@ __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, 
                                             uint32_t rid, int x, int y, uint32_t clr) {
     if (f.level >= 0) { w.lvl_clr[(size_t)f.level * w.n + rid] = clr; return; }
     if (f.alias > 0) { w.rec_sum[rid] = clr; return; }
-    size_t i = ((size_t)(y + f.row_begin) * (size_t)f.width + (size_t)x) * 3;
+    size_t i = ((size_t)frame_row(f, y) * (size_t)f.width + (size_t)x) * 3;
     pixmap[i] = (unsigned char)cr(clr); pixmap[i + 1] = (unsigned char)cg(clr); pixmap[i + 2] = (unsigned char)cb(clr);
 }
 // CalcPixel's average over the alias x alias sub-samples of a pixel (main.cpp:315-325): sums of the
@@ -1607,7 +1616,7 @@ __global__ __launch_bounds__(256) void k_average(Frame f, const uint32_t *__rest
             red += (double)(int)cr(clr); green += (double)(int)cg(clr); blue += (double)(int)cb(clr);
         }
     const double n = (double)(f.alias * f.alias);
-    const size_t i = ((size_t)(y + f.row_begin) * (size_t)f.width + (size_t)x) * 3;
+    const size_t i = ((size_t)frame_row(f, y) * (size_t)f.width + (size_t)x) * 3;
     pixmap[i] = (unsigned char)q8(red / n); pixmap[i + 1] = (unsigned char)q8(green / n); pixmap[i + 2] = (unsigned char)q8(blue / n);
 }
 
@@ -2071,9 +2080,9 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
         const HitGeo h = hit_geometry(s, e, c);
         const uint32_t cm0 = s.objects[h.obj].rgb;
         // the sub-sample this hit belongs to keys the two random numbers
-        int px = x, py = y + f.row_begin, sample = 0;
+        int px = x, py = frame_row(f, y), sample = 0;
         if (f.alias > 0) {
-            px = x / f.alias; py = y / f.alias + f.row_begin;
+            px = x / f.alias; py = frame_row(f, y / f.alias);
             sample = (y % f.alias) * f.alias + x % f.alias;
         }
         const double theta1 = rt355x_rotation(f.seed, px, py, sample, 0) * 2 * RT_PI; // shader.h:106-109,149-152
@@ -2217,9 +2226,9 @@ __global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w) {
     if (rid >= f.n_rays || w.rec_obj[rid] < 0) return;
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
-    int px = x, py = y + f.row_begin, sample = 0; // the sub-sample this hit belongs to keys the two random numbers
+    int px = x, py = frame_row(f, y), sample = 0; // the sub-sample this hit belongs to keys the two random numbers
     if (f.alias > 0) {
-        px = x / f.alias; py = y / f.alias + f.row_begin;
+        px = x / f.alias; py = frame_row(f, y / f.alias);
         sample = (y % f.alias) * f.alias + x % f.alias;
     }
     const double theta1 = rt355x_rotation(f.seed, px, py, sample, 0) * 2 * RT_PI; // shader.h:106-109,149-152
@@ -2667,6 +2676,12 @@ struct rt355_scene {
     double tune_ms[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
     int forced_packet_rays = 0; // RT355_PACKET_RAYS=1|4 pins the choice (tests)
     std::vector<std::pair<int, int>> launch_choice; // (kind of launch, rays per lane) per search launch
+    // rt355_render (host pixmap): the device framebuffer kept from call to call, the stream the readback runs on
+    // beside the rendering of the next part of the frame, and page-locked staging for pixmaps that are pageable
+    unsigned char *fb = nullptr; size_t fb_bytes = 0;
+    unsigned char *stage = nullptr; size_t stage_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> ev_copy;
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
     uint64_t pending_primary = 0, pending_pairs_static = 0;
@@ -2953,15 +2968,15 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     kind_prims.insert(kind_prims.end(), by_kind[4].begin(), by_kind[4].end());
     kind_prims.insert(kind_prims.end(), by_kind[2].begin(), by_kind[2].end());
     rt355_scene *sc = new rt355_scene();
+    // everything after `new` runs inside one function, so that any failure takes the one cleanup path below
+    auto init = [&]() -> int {
     HIP_TRY(hipGetDevice(&sc->device));
     int rc;
     if ((rc = upload(sc, kind_prims, &sc->view.kind_prims)) || (rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
         (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
         (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || (rc = upload(sc, quadrics, &sc->view.quadrics)) ||
-        (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels))) {
-        rt355_scene_destroy(sc);
+        (rc = upload(sc, tex, &sc->view.textures)) || (rc = upload(sc, pool, &sc->view.texels)))
         return rc;
-    }
     sc->view.n_objects = d->n_objects;
     sc->view.n_prims = (int)prim_obj.size();
     sc->view.n_planes = (int)by_kind[0].size(); sc->view.n_spheres = (int)by_kind[1].size();
@@ -2982,10 +2997,8 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->ks_abs_max = ks_abs_max;
     sc->rmax = rmax; sc->extent = extent;
     sc->view.far_origin = std::min(FAR_ORIGIN, FAR_SCALE * (1.0 + extent + rmax));
-    if (sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri))) {
-        rt355_scene_destroy(sc);
+    if (sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri)))
         return rc;
-    }
     HIP_TRY(hipEventCreate(&sc->ev_begin));
     HIP_TRY(hipEventCreate(&sc->ev_end));
     HIP_TRY(hipEventCreate(&sc->ev_done));
@@ -2994,6 +3007,22 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     HIP_TRY(hipMalloc(&ctr, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     sc->owned.push_back(ctr);
     sc->work.counters = (unsigned long long *)ctr;
+    for (int i = 0; i < 2; i++) { // the event pairs every frame needs (frames with more launches add theirs in ensure_work)
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        sc->ev_search.push_back(e);
+        HIP_TRY(hipEventCreate(&e));
+        sc->ev_resolve.push_back(e);
+    }
+    return RT355_OK;
+    };
+    const int rc_init = init();
+    if (rc_init != RT355_OK) {
+        const std::string why = g_err; // (the clean-up's own HIP calls must not replace the message)
+        rt355_scene_destroy(sc);
+        g_err = why;
+        return rc_init;
+    }
     *out = sc;
     return RT355_OK;
 }
@@ -3035,6 +3064,10 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
     if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
     if (sc->host_counters) (void)hipHostFree(sc->host_counters);
+    if (sc->copy_stream) { (void)hipStreamSynchronize(sc->copy_stream); (void)hipStreamDestroy(sc->copy_stream); }
+    if (sc->fb) (void)hipFree(sc->fb);
+    if (sc->stage) (void)hipHostFree(sc->stage);
+    for (hipEvent_t e : sc->ev_copy) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->ev_search) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->ev_resolve) (void)hipEventDestroy(e);
     delete sc;
@@ -3130,15 +3163,56 @@ static DCamera set_camera(const rt355_camera *c) { // Scene::SetCamera, main.cpp
     return o;
 }
 
-extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
-                                   const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
+// The rows a call renders: the slab [row_begin, row_end), or its share of the slab's row tiles.
+struct Rows { int y0, y1, count; };
+static int rows_of(const rt355_opts *opts, Rows *out) {
+    int y0 = opts->row_begin, y1 = opts->row_end;
+    if (y0 == 0 && y1 == 0) y1 = opts->height;
+    if (y0 < 0 || y1 > opts->height || y0 >= y1) return fail(RT355_ERR_ARG, "row slab out of range");
+    int count = y1 - y0;
+    if (opts->tile_count > 1) {
+        if (opts->tile_rows <= 0 || opts->tile_phase < 0 || opts->tile_phase >= opts->tile_count)
+            return fail(RT355_ERR_ARG, "row tiles: tile_rows > 0 and 0 <= tile_phase < tile_count");
+        count = 0;
+        for (int k = opts->tile_phase; k * opts->tile_rows < y1 - y0; k += opts->tile_count)
+            count += std::min(opts->tile_rows, y1 - y0 - k * opts->tile_rows);
+    }
+    out->y0 = y0; out->y1 = y1; out->count = count;
+    return RT355_OK;
+}
+
+// The level / gather arrays of the workspace: all five or none (a frame that needs them launches kernels on all).
+static int ensure_levels(rt355_scene *sc) {
+    Work &wk = sc->work;
+    if (wk.lvl_clr && wk.lvl_ks && wk.ktotal && wk.deepest && wk.ray_d) return RT355_OK;
+    const size_t cap = sc->work_rays;
+    auto drop = [&]() {
+        void *ps[] = {wk.lvl_clr, wk.lvl_ks, wk.ktotal, wk.deepest, wk.ray_d};
+        for (void *q : ps) if (q) (void)hipFree(q);
+        wk.lvl_clr = nullptr; wk.lvl_ks = nullptr; wk.ktotal = nullptr; wk.deepest = nullptr; wk.ray_d = nullptr;
+    };
+    drop();
+    hipError_t e;
+    if ((e = hipMalloc((void **)&wk.lvl_clr, 4 * cap * sizeof(uint32_t))) == hipSuccess &&
+        (e = hipMalloc((void **)&wk.lvl_ks, 4 * cap * sizeof(double))) == hipSuccess &&
+        (e = hipMalloc((void **)&wk.ktotal, cap * sizeof(double))) == hipSuccess &&
+        (e = hipMalloc((void **)&wk.deepest, cap * sizeof(uint32_t))) == hipSuccess &&
+        (e = hipMalloc((void **)&wk.ray_d, 6 * cap * sizeof(double))) == hipSuccess)
+        return RT355_OK;
+    drop();
+    return fail(RT355_ERR_DEVICE, std::string("level arrays: ") + hipGetErrorString(e));
+}
+
+// One frame (or slab) enqueued on `hip_stream`.
+static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
+                          const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
     if (!sc || !cam || !shader || !opts || !d_pixmap) return fail(RT355_ERR_ARG, "rt355_render_device: null argument");
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
     if (opts->alias < 0 || opts->alias > 64) return fail(RT355_ERR_ARG, "alias must be 0..64");
     if (shader->n_lights < 0 || (shader->n_lights && !shader->lights)) return fail(RT355_ERR_ARG, "bad light list");
-    int y0 = opts->row_begin, y1 = opts->row_end;
-    if (y0 == 0 && y1 == 0) y1 = opts->height;
-    if (y0 < 0 || y1 > opts->height || y0 >= y1) return fail(RT355_ERR_ARG, "row slab out of range");
+    Rows rows;
+    { int rc0 = rows_of(opts, &rows); if (rc0) return rc0; }
+    const int y0 = rows.y0;
     if (opts->mode != RT355_MODE_ALLPAIRS && opts->mode != RT355_MODE_BRUTE && opts->mode != RT355_MODE_PACKET)
         return fail(RT355_ERR_ARG, "unknown mode");
     if (opts->shading != RT355_SHADING_LIGHTS && opts->shading != RT355_SHADING_OCCLUSION && opts->shading != RT355_SHADING_BLEED)
@@ -3146,9 +3220,16 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     HIP_TRY(hipSetDevice(sc->device));
     if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     hipStream_t st = (hipStream_t)hip_stream;
+    if (rows.count == 0) { // a share without tiles (more shares than the slab has tiles): nothing to render
+        if (stats) memset(stats, 0, sizeof *stats);
+        return RT355_OK;
+    }
 
     Frame f;
-    f.width = opts->width; f.height = opts->height; f.row_begin = y0; f.rows = y1 - y0;
+    f.width = opts->width; f.height = opts->height; f.row_begin = y0; f.rows = rows.count;
+    f.tile_rows = opts->tile_count > 1 ? opts->tile_rows : 1;
+    f.tile_count = opts->tile_count > 1 ? opts->tile_count : 1;
+    f.tile_phase = opts->tile_count > 1 ? opts->tile_phase : 0;
     f.alias = opts->alias; f.seed = opts->seed;
     const int64_t sub = opts->alias > 0 ? opts->alias : 1;
     const int64_t grid_w = f.width * sub, grid_h = f.rows * sub;
@@ -3175,17 +3256,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     }
     const bool levels = extra_levels > 0;
     const bool gather_searched = can_search && opts->shading != RT355_SHADING_LIGHTS;
-    int rc = ensure_work(sc, f.n_rays, slots, (1 + 2 * n_groups) * (1 + extra_levels), (1 + n_groups) * (1 + extra_levels) - 1);
+    // search launches: the camera rays and two per group of lights, per level; the gather passes record two pairs
+    const int n_search = std::max((1 + 2 * n_groups) * (1 + extra_levels), gather_searched ? 2 : 1);
+    int rc = ensure_work(sc, f.n_rays, slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1);
     if (rc) return rc;
-    if ((levels || gather_searched) && !sc->work.lvl_clr) {
-        const size_t cap = sc->work_rays;
-        Work &wk = sc->work;
-        HIP_TRY(hipMalloc((void **)&wk.lvl_clr, 4 * cap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&wk.lvl_ks, 4 * cap * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&wk.ktotal, cap * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&wk.deepest, cap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&wk.ray_d, 6 * cap * sizeof(double)));
-    }
+    if ((levels || gather_searched) && (rc = ensure_levels(sc))) return rc;
 
     // lights -> device
     std::vector<DLight> hl(nl);
@@ -3199,7 +3274,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         put3(hl[i].shadow_dir, hnormalize(hmul(H3(l.direction), -1.0)));
     }
     if (nl > sc->lights_cap) {
-        if (sc->d_lights) (void)hipFree(sc->d_lights);
+        if (sc->d_lights) { (void)hipFree(sc->d_lights); sc->d_lights = nullptr; sc->lights_cap = 0; }
         HIP_TRY(hipMalloc((void **)&sc->d_lights, (size_t)nl * sizeof(DLight)));
         sc->lights_cap = nl;
     }
@@ -3214,7 +3289,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     const bool gather = opts->shading != RT355_SHADING_LIGHTS;
     if (gather_searched && !sc->has_general) return fail(RT355_ERR_ARG, "internal: the scene table for gather rays is missing");
     if (levels && !sc->has_general) return fail(RT355_ERR_ARG, "internal: the scene table for mirror rays is missing");
-    std::vector<Bundle> bundles(2 + nl);
+    std::vector<Bundle> bundles(can_search ? 2 + nl : 0); // (unsearched frames have none: no allocation on that path)
     for (auto &b : bundles) memset(&b, 0, sizeof b);
     if (can_search) {
         bundles[0].kind = 1;
@@ -3240,19 +3315,19 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         }
     }
 
-    if (opts->mode == RT355_MODE_PACKET)
+    if (can_search && opts->mode == RT355_MODE_PACKET)
         for (int k = 0; k < nl; k++)
             if (bundles[1 + k].kind) bundles[1 + k].binned = 1;
 
+    const Work &w = sc->work;
     HIP_TRY(hipEventRecord(sc->ev_begin, st));
-    HIP_TRY(hipMemsetAsync(sc->work.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(w.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
     const unsigned per_ray_blocks = (f.n_rays + 255) / 256;
     const unsigned table_blocks = (unsigned)(sc->n_table / 256);            // one thread per table row
     const unsigned top_blocks = (unsigned)(sc->tables.top_stride * 64 / 256); // one thread per chunk, padding included
     const unsigned n_tiles = (unsigned)(f.tiles_x * f.tiles_y);
     unsigned char *pix = (unsigned char *)d_pixmap;
     int launches = 0;
-    const Work &w = sc->work;
     sc->launch_choice.clear();
     // rays per lane for a kind of launch: try 4, then 1, then keep the faster
     auto packet_rays_for = [&](int cls) -> int {
@@ -3514,7 +3589,7 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
         hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, st));
-    HIP_TRY(hipMemcpyAsync(sc->host_counters, sc->work.counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long),
+    HIP_TRY(hipMemcpyAsync(sc->host_counters, w.counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(sc->ev_done, st));
     sc->pending = true;
@@ -3525,6 +3600,11 @@ extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, con
     sc->search_launches = launches;
     sc->resolve_launches = can_search ? resolves : 1;
     return RT355_OK;
+}
+
+extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
+                                   const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
+    return render_enqueue(sc, cam, shader, opts, d_pixmap, hip_stream, stats);
 }
 
 extern "C" int rt355_scene_sync(rt355_scene *sc) {
@@ -3623,24 +3703,123 @@ extern "C" int rt355_scene_search_launch_ms(rt355_scene *sc, int32_t index, doub
     return RT355_OK;
 }
 
+// Page-locked host memory for the pixmap of rt355_render.
+extern "C" void *rt355_host_alloc(uint64_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        g_err = "rt355_host_alloc: hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void rt355_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+static bool host_is_pinned(const void *p) { // page-locked memory the runtime knows (hipHostMalloc, hipHostRegister)
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// setPixels' replacement (main.cpp:339-376): render into the handle's device framebuffer, read back into the
+// caller's pixmap.  The frame is rendered in a few parts (whole rows), and the readback of a part runs on a
+// second stream while the next part renders; a page-locked pixmap is the target of the DMA itself, any other
+// is filled from page-locked staging memory, the host copy of a part overlapping the transfer of the next.
+// Nothing is allocated per frame: framebuffer and staging grow when a larger frame comes and are kept.
+#define RENDER_PARTS_MAX 8
 extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                             const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats) {
     if (!sc || !opts || !pixmap) return fail(RT355_ERR_ARG, "rt355_render: null argument");
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
     HIP_TRY(hipSetDevice(sc->device));
-    size_t bytes = (size_t)opts->width * opts->height * 3;
-    void *d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
-    int rc = rt355_render_device(sc, cam, shader, opts, d, nullptr, stats);
-    if (rc == RT355_OK) rc = rt355_scene_sync(sc);
-    if (rc == RT355_OK) {
-        int y0 = opts->row_begin, y1 = opts->row_end;
-        if (y0 == 0 && y1 == 0) y1 = opts->height;
-        size_t off = (size_t)y0 * opts->width * 3, len = (size_t)(y1 - y0) * opts->width * 3;
-        hipError_t e = hipMemcpy(pixmap + off, (unsigned char *)d + off, len, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
+    Rows rows;
+    { int rc0 = rows_of(opts, &rows); if (rc0) return rc0; }
+    const size_t row_bytes = (size_t)opts->width * 3, bytes = row_bytes * (size_t)opts->height;
+    if (bytes > sc->fb_bytes) {
+        if (sc->fb) { (void)hipFree(sc->fb); sc->fb = nullptr; sc->fb_bytes = 0; }
+        HIP_TRY(hipMalloc((void **)&sc->fb, bytes));
+        sc->fb_bytes = bytes;
     }
-    (void)hipFree(d);
+    if (!sc->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream, hipStreamNonBlocking));
+    while (sc->ev_copy.size() < RENDER_PARTS_MAX) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sc->ev_copy.push_back(e);
+    }
+    const bool pinned = host_is_pinned(pixmap);
+    if (!pinned && bytes > sc->stage_bytes) {
+        if (sc->stage) { (void)hipHostFree(sc->stage); sc->stage = nullptr; sc->stage_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&sc->stage, bytes, hipHostMallocDefault));
+        sc->stage_bytes = bytes;
+    }
+    // parts: whole multiples of 32 rows (the tile height of the ray numbering divides it), at least 256 rows each;
+    // a call that renders a share of interleaved row tiles is one part
+    int n_parts = 1;
+    const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS;
+    if (opts->tile_count <= 1) {
+        n_parts = searched ? 2 : 4;
+        if (const char *e = getenv("RT355_RENDER_PARTS")) n_parts = atoi(e);
+        n_parts = std::max(1, std::min(n_parts, std::min(RENDER_PARTS_MAX, (rows.y1 - rows.y0) / 256)));
+    }
+    rt355_stats total;
+    memset(&total, 0, sizeof total);
+    int part_y0[RENDER_PARTS_MAX + 1];
+    for (int i = 0; i <= n_parts; i++) {
+        part_y0[i] = rows.y0 + (int)((int64_t)(rows.y1 - rows.y0) * i / n_parts) / 32 * 32;
+        if (i == 0) part_y0[i] = rows.y0;
+        if (i == n_parts) part_y0[i] = rows.y1;
+    }
+    unsigned char *host_dst = pinned ? pixmap : sc->stage;
+    // the rows a part (or a share's tile) covers go back as one transfer each
+    auto read_back = [&](int ya, int yb, hipEvent_t done) -> int {
+        if (opts->tile_count > 1) {
+            for (int k = opts->tile_phase; k * opts->tile_rows < yb - ya; k += opts->tile_count) {
+                const int ta = ya + k * opts->tile_rows, tb = std::min(yb, ta + opts->tile_rows);
+                HIP_TRY(hipMemcpyAsync(host_dst + ta * row_bytes, sc->fb + ta * row_bytes, (size_t)(tb - ta) * row_bytes, hipMemcpyDeviceToHost, sc->copy_stream));
+            }
+        } else {
+            HIP_TRY(hipMemcpyAsync(host_dst + ya * row_bytes, sc->fb + ya * row_bytes, (size_t)(yb - ya) * row_bytes, hipMemcpyDeviceToHost, sc->copy_stream));
+        }
+        HIP_TRY(hipEventRecord(done, sc->copy_stream));
+        return RT355_OK;
+    };
+    auto to_pixmap = [&](int ya, int yb) { // staged rows -> the caller's pageable pixmap
+        if (opts->tile_count > 1) {
+            for (int k = opts->tile_phase; k * opts->tile_rows < yb - ya; k += opts->tile_count) {
+                const int ta = ya + k * opts->tile_rows, tb = std::min(yb, ta + opts->tile_rows);
+                memcpy(pixmap + ta * row_bytes, sc->stage + ta * row_bytes, (size_t)(tb - ta) * row_bytes);
+            }
+        } else {
+            memcpy(pixmap + ya * row_bytes, sc->stage + ya * row_bytes, (size_t)(yb - ya) * row_bytes);
+        }
+    };
+    int rc = RT355_OK;
+    int copies_in_flight = 0; // parts whose transfer was enqueued
+    for (int i = 0; i < n_parts && rc == RT355_OK; i++) {
+        rt355_opts part = *opts;
+        part.row_begin = part_y0[i]; part.row_end = part_y0[i + 1];
+        rt355_stats st;
+        memset(&st, 0, sizeof st);
+        rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, &st);
+        if (rc == RT355_OK && !pinned && i > 0) { // meanwhile: the part before this one, from staging to the pixmap
+            hipError_t e = hipEventSynchronize(sc->ev_copy[i - 1]);
+            if (e != hipSuccess) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
+            else to_pixmap(part_y0[i - 1], part_y0[i]);
+        }
+        if (rc == RT355_OK) rc = rt355_scene_sync(sc);
+        if (rc != RT355_OK) break;
+        total.primary_rays += st.primary_rays; total.shadow_rays += st.shadow_rays; total.pair_tests += st.pair_tests;
+        total.exact_tests += st.exact_tests; total.overflow_rays += st.overflow_rays; total.ms_device += st.ms_device;
+        total.packet_survivors += st.packet_survivors; total.primary_hits += st.primary_hits;
+        total.secondary_rays += st.secondary_rays; total.gather_rays += st.gather_rays;
+        rc = read_back(part_y0[i], part_y0[i + 1], sc->ev_copy[i]);
+        if (rc == RT355_OK) copies_in_flight = i + 1;
+    }
+    // (on an error too: no transfer into the caller's memory may outlive the call)
+    hipError_t e = hipStreamSynchronize(sc->copy_stream);
+    if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
+    if (rc == RT355_OK && !pinned && copies_in_flight == n_parts) to_pixmap(part_y0[n_parts - 1], part_y0[n_parts]);
+    if (rc == RT355_OK && stats) *stats = total;
     return rc;
 }
 
@@ -3671,14 +3850,19 @@ extern "C" int rt355_probe_sincos(const double *x, int n, double *out) {
     for (int i = 0; i < n; i++)
         if (!(x[i] >= 0 && x[i] < 8)) return fail(RT355_ERR_ARG, "rt355_probe_sincos: 0 <= x < 8");
     double *dx = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void **)&dx, (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 2 * sizeof(double)));
-    HIP_TRY(hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_sincos, dim3((n + 127) / 128), dim3(128), 0, 0, dx, n, dout);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dout);
-    return RT355_OK;
+    auto run = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&dx, (size_t)n * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 2 * sizeof(double)));
+        HIP_TRY(hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_probe_sincos, dim3((n + 127) / 128), dim3(128), 0, 0, dx, n, dout);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out, dout, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        return RT355_OK;
+    };
+    const int rc = run();
+    if (dx) (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+    return rc;
 }
 
 // Debug probe: objs[obj]->CalcIntersect for n host rays (n x 6 doubles) -> n x 9 doubles
@@ -3687,12 +3871,17 @@ extern "C" int rt355_probe_intersect(rt355_scene *sc, int obj, const double *ray
     if (!sc || !rays || !out || n <= 0 || obj < 0 || obj >= sc->view.n_objects) return fail(RT355_ERR_ARG, "rt355_probe_intersect: bad argument");
     HIP_TRY(hipSetDevice(sc->device));
     double *dr = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void **)&dr, (size_t)n * 6 * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 9 * sizeof(double)));
-    HIP_TRY(hipMemcpy(dr, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_probe_intersect, dim3((n + 127) / 128), dim3(128), 0, 0, sc->view, obj, dr, n, dout);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(dr); (void)hipFree(dout);
-    return RT355_OK;
+    auto run = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&dr, (size_t)n * 6 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 9 * sizeof(double)));
+        HIP_TRY(hipMemcpy(dr, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_probe_intersect, dim3((n + 127) / 128), dim3(128), 0, 0, sc->view, obj, dr, n, dout);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out, dout, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+        return RT355_OK;
+    };
+    const int rc = run();
+    if (dr) (void)hipFree(dr);
+    if (dout) (void)hipFree(dout);
+    return rc;
 }

@@ -17,7 +17,7 @@ def _worker(rank, world, port, out_dir):
     from oracle.oracle_py import Oracle
     from raytracer_amd import binding as B
     from raytracer_amd import scenes as S
-    from raytracer_amd.sharding import frames_for_rank, gather_frame, slab_rows
+    from raytracer_amd.sharding import frames_for_rank, gather_frame, slab_rows, tile_rows_of
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,6 +33,16 @@ def _worker(rank, world, port, out_dir):
         np.save(os.path.join(out_dir, "slabs.npy"), full.numpy())
     else:
         assert full is None
+    # interleaved row tiles of 16 rows: the call renders this rank's share in place, one gather assembles the frame
+    local = np.zeros((h, w, 3), dtype=np.uint8)
+    O.render(p, cam, sh, B.opts(w, h, tile_rows=16, tile_count=world, tile_phase=rank), threads=2, out=local)
+    mine = np.zeros(h, dtype=bool)
+    for tb, te in tile_rows_of(h, world, rank, 16):
+        mine[tb:te] = True
+    assert not local[~mine].any() and local[mine].any()
+    full = gather_frame(torch.from_numpy(local), rank, world, dst=0, shard="tiles", tile_rows=16)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "tiles.npy"), full.numpy())
     # camera sweep: frame f on rank f mod world, hashes exchanged only to check the partition
     mine = frames_for_rank(5, rank, world)
     hashes = torch.zeros(5, dtype=torch.int64)
@@ -57,6 +67,7 @@ def test_slabs_and_sweep_world2(tmp_path, oracle):
     want, _ = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=2)
     got = np.load(tmp_path / "slabs.npy")
     assert np.array_equal(got, want)
+    assert np.array_equal(np.load(tmp_path / "tiles.npy"), want)
     sweep = np.load(tmp_path / "sweep.npy")
     for f in range(5):
         frame, _ = oracle.render(sc.pack(), S.orbit_camera(f, 48, 32, n_frames=5, center=(0, 0, 0), radius=30, eye_z=8),
@@ -78,3 +89,49 @@ def test_slab_rows_cover_frame():
     assert sorted(sum((frames_for_rank(60, r, 8) for r in range(8)), [])) == list(range(60))
     with pytest.raises(ValueError):
         slab_rows(0, 2)
+    with pytest.raises(ValueError):   # an empty slab would read as "the whole frame" at the C ABI
+        slab_rows(3, 8)
+
+
+def test_tile_shares_cover_frame():
+    from raytracer_amd.sharding import rows_of, tile_rows_of
+    for h in (1, 31, 32, 33, 600, 2160, 4320):
+        for n in (1, 2, 3, 8):
+            for t in (1, 7, 32):
+                seen = np.zeros(h, dtype=int)
+                for r in range(n):
+                    for b, e in tile_rows_of(h, n, r, t):
+                        assert 0 <= b < e <= h and b % t == 0 and (b // t) % n == r
+                        seen[b:e] += 1
+                assert (seen == 1).all()
+    assert rows_of(2160, 8, 3, "slabs") == [(810, 1080)]
+    assert rows_of(2160, 8, 3, "tiles")[:2] == [(96, 128), (352, 384)]
+
+
+def test_checker_renders_tile_shares(oracle):
+    """The checker's side of rt355_opts.tile_*: the shares together are the frame, each leaves the other rows alone."""
+    from raytracer_amd import binding as B
+    from raytracer_amd import scenes as S
+    sc, sh, cam, w, h = S.small_case("default_2lights")
+    want, _ = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=2, seed=3), threads=2)
+    got = np.zeros_like(want)
+    rays = 0
+    for g in range(3):
+        _, st = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=2, seed=3, tile_rows=20, tile_count=3, tile_phase=g),
+                              threads=2, out=got)
+        rays += st["primary_rays"]
+    assert np.array_equal(got, want) and rays == w * h * 4
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the script spawns the ranks itself (before it touches a GPU)
+    and rank 0 prints the one line.  --check-launch stops after the ranks have met, so this runs without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"launch": "ok", "n_gpus": 2, "rank_sum": 3.0}
