@@ -241,6 +241,24 @@ int rt355_render_device(rt355_scene *scene, const rt355_camera *cam,
                         const rt355_shader *shader, const rt355_opts *opts,
                         void *d_pixmap, void *hip_stream, rt355_stats *stats);
 
+/* rt355_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  It calls no hipMalloc / hipFree /
+ * hipHostMalloc or other allocating routine: the device memory the kernels need beyond the scene, the
+ * lights and the pixmap -- the statistics counters, the device copy of the light list and, with alias > 0,
+ * the sub-sample colours -- lives in an array inside the library's code object (RT355_NOALLOC_BYTES, about
+ * 16 MiB per GPU, held until the process ends).  Limits (RT355_ERR_UNSUPPORTED beyond them, with a
+ * message): only frames that are rendered without a search -- scenes of fewer than 64 primitives, or
+ * mode RT355_MODE_BRUTE -- at most RT355_NOALLOC_MAX_LIGHTS lights and, with alias > 0, at most
+ * RT355_NOALLOC_MAX_SUBSAMPLES sub-samples per call (split the frame into row slabs to stay below).
+ * Every call on a GPU uses that GPU's one array: calls on one GPU that overlap in time (two streams, two
+ * host threads, two scene handles) race; calls that follow one another on a stream do not.  Pixels,
+ * statistics and error behaviour are those of rt355_render_device. */
+#define RT355_NOALLOC_MAX_LIGHTS 64
+#define RT355_NOALLOC_MAX_SUBSAMPLES (1 << 22)
+int rt355_render_device_noalloc(rt355_scene *scene, const rt355_camera *cam,
+                                const rt355_shader *shader, const rt355_opts *opts,
+                                void *d_pixmap, void *hip_stream, rt355_stats *stats);
+
 /* Page-locked host memory for the pixmap handed to rt355_render (in place of `new unsigned char[...]`,
  * main.cpp:544): the readback is then one DMA transfer straight into the caller's buffer.  rt355_render
  * accepts any host pointer; one that is not page-locked is filled through a staging buffer at the cost

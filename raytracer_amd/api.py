@@ -42,6 +42,7 @@ def lib():
         L.rt355_scene_destroy.restype = None
         L.rt355_render.argtypes = [C.c_void_p] * 6
         L.rt355_render_device.argtypes = [C.c_void_p] * 7
+        L.rt355_render_device_noalloc.argtypes = [C.c_void_p] * 7
         L.rt355_host_alloc.restype = C.c_void_p
         L.rt355_host_alloc.argtypes = [C.c_uint64]
         L.rt355_host_free.restype = None
@@ -108,6 +109,12 @@ class Renderer:
         _check(lib().rt355_render_device(self.handle, C.byref(cam), C.byref(shader.c), C.byref(o),
                                          C.c_void_p(d_pixmap), C.c_void_p(stream), C.byref(self._stats)),
                "rt355_render_device")
+
+    def render_device_noalloc(self, cam, shader: Shader, o: COpts, d_pixmap: int, stream: int = 0):
+        """rt355_render_device_noalloc: the same for callers that cannot allocate (unsearched frames only)."""
+        _check(lib().rt355_render_device_noalloc(self.handle, C.byref(cam), C.byref(shader.c), C.byref(o),
+                                                 C.c_void_p(d_pixmap), C.c_void_p(stream), C.byref(self._stats)),
+               "rt355_render_device_noalloc")
 
     def sync(self) -> dict:
         _check(lib().rt355_scene_sync(self.handle), "rt355_scene_sync")

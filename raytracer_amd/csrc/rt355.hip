@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -2703,6 +2704,40 @@ extern "C" int rt355_sincos(double x, double *sin_out, double *cos_out) {
     return RT355_OK;
 }
 
+// ---- the array of rt355_render_device_noalloc ---------------------------------------------------------------
+// Device memory for callers that cannot allocate: the statistics counters, the device copy of the light list
+// and the sub-sample colours of a supersampled frame, in one array of the library's code object.  Each GPU
+// holds its own copy at its own address; `scratch` below is only the host-side name of the symbol, so the
+// address is asked for once per device (noalloc_bind, from rt355_scene_create with that device current) and
+// everything -- kernel arguments, hipMemsetAsync, copies -- goes through the pointer kept here.
+#define NOALLOC_COUNTER_BYTES ((size_t)COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long))
+#define NOALLOC_LIGHT_BYTES ((size_t)RT355_NOALLOC_MAX_LIGHTS * sizeof(DLight))
+#define NOALLOC_LIGHTS_AT ((NOALLOC_COUNTER_BYTES + 255) / 256 * 256)
+#define NOALLOC_SUB_AT ((NOALLOC_LIGHTS_AT + NOALLOC_LIGHT_BYTES + 255) / 256 * 256)
+#define RT355_NOALLOC_BYTES (NOALLOC_SUB_AT + (size_t)RT355_NOALLOC_MAX_SUBSAMPLES * sizeof(uint32_t))
+static __device__ __align__(256) unsigned char scratch[RT355_NOALLOC_BYTES];
+#define NOALLOC_MAX_DEVICES 64
+static unsigned char *g_noalloc_ptr[NOALLOC_MAX_DEVICES]; // per device: where its copy of the array lies
+static std::mutex g_noalloc_mutex;
+static int noalloc_bind(int device) { // the current device is `device`
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return RT355_OK; // (no such machine; the entry point then refuses)
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (g_noalloc_ptr[device]) return RT355_OK;
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(RT355_ERR_DEVICE, "hipGetSymbolAddress gave no address for the no-alloc array");
+    g_noalloc_ptr[device] = (unsigned char *)ptr;
+    return RT355_OK;
+}
+// the light list travels as a kernel argument (a copy from pageable host memory may stage through memory the
+// runtime allocates): up to LIGHT_PACK lights per launch
+#define LIGHT_PACK 16
+struct LightPack { DLight l[LIGHT_PACK]; };
+__global__ void k_put_lights(LightPack pack, DLight *__restrict__ dst, int first, int count) {
+    const int i = threadIdx.x;
+    if (i < count) dst[first + i] = pack.l[i];
+}
+
 template <typename T>
 static int upload(rt355_scene *sc, const std::vector<T> &v, const T **out) {
     void *p = nullptr;
@@ -2972,6 +3007,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     auto init = [&]() -> int {
     HIP_TRY(hipGetDevice(&sc->device));
     int rc;
+    if ((rc = noalloc_bind(sc->device))) return rc;
     if ((rc = upload(sc, kind_prims, &sc->view.kind_prims)) || (rc = upload(sc, objs, &sc->view.objects)) || (rc = upload(sc, tris, &sc->view.tris)) ||
         (rc = upload(sc, prim_obj, &sc->view.prim_obj)) || (rc = upload(sc, prim_tri, &sc->view.prim_tri)) ||
         (rc = upload(sc, prim_rec, &sc->view.prim_rec)) || (rc = upload(sc, quadrics, &sc->view.quadrics)) ||
@@ -3203,9 +3239,10 @@ static int ensure_levels(rt355_scene *sc) {
     return fail(RT355_ERR_DEVICE, std::string("level arrays: ") + hipGetErrorString(e));
 }
 
-// One frame (or slab) enqueued on `hip_stream`.
+// One frame (or slab) enqueued on `hip_stream`.  noalloc: the entry point that allocates nothing -- the counters,
+// the lights and the sub-sample colours live in the static array, and frames that need the workspace are refused.
 static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
-                          const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
+                          const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats, bool noalloc) {
     if (!sc || !cam || !shader || !opts || !d_pixmap) return fail(RT355_ERR_ARG, "rt355_render_device: null argument");
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
     if (opts->alias < 0 || opts->alias > 64) return fail(RT355_ERR_ARG, "alias must be 0..64");
@@ -3256,14 +3293,32 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     }
     const bool levels = extra_levels > 0;
     const bool gather_searched = can_search && opts->shading != RT355_SHADING_LIGHTS;
-    // search launches: the camera rays and two per group of lights, per level; the gather passes record two pairs
-    const int n_search = std::max((1 + 2 * n_groups) * (1 + extra_levels), gather_searched ? 2 : 1);
-    int rc = ensure_work(sc, f.n_rays, slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1);
-    if (rc) return rc;
-    if ((levels || gather_searched) && (rc = ensure_levels(sc))) return rc;
+    int rc = RT355_OK;
+    unsigned char *na = nullptr; // the no-alloc array of this device
+    if (noalloc) {
+        if (can_search)
+            return fail(RT355_ERR_UNSUPPORTED, "rt355_render_device_noalloc: this frame is searched (64 primitives or more) and needs "
+                        "the per-ray workspace; use RT355_MODE_BRUTE or rt355_render_device");
+        if (nl > RT355_NOALLOC_MAX_LIGHTS)
+            return fail(RT355_ERR_UNSUPPORTED, "rt355_render_device_noalloc: more than " + std::to_string(RT355_NOALLOC_MAX_LIGHTS) + " lights");
+        if (f.alias > 0 && f.n_rays > (uint32_t)RT355_NOALLOC_MAX_SUBSAMPLES)
+            return fail(RT355_ERR_UNSUPPORTED, "rt355_render_device_noalloc: " + std::to_string(f.n_rays) + " sub-samples in one call, the limit is " +
+                        std::to_string(RT355_NOALLOC_MAX_SUBSAMPLES) + ": render the frame in row slabs");
+        na = (sc->device >= 0 && sc->device < NOALLOC_MAX_DEVICES) ? g_noalloc_ptr[sc->device] : nullptr;
+        if (!na) return fail(RT355_ERR_DEVICE, "rt355_render_device_noalloc: the no-alloc array of this device was not bound");
+    } else {
+        // search launches: the camera rays and two per group of lights, per level; the gather passes record two pairs
+        const int n_search = std::max((1 + 2 * n_groups) * (1 + extra_levels), gather_searched ? 2 : 1);
+        rc = ensure_work(sc, f.n_rays, slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1);
+        if (rc) return rc;
+        if ((levels || gather_searched) && (rc = ensure_levels(sc))) return rc;
+    }
 
     // lights -> device
-    std::vector<DLight> hl(nl);
+    DLight hl_fixed[RT355_NOALLOC_MAX_LIGHTS];
+    std::vector<DLight> hl_grown;
+    if (nl > RT355_NOALLOC_MAX_LIGHTS) hl_grown.resize(nl);
+    DLight *hl = nl > RT355_NOALLOC_MAX_LIGHTS ? hl_grown.data() : hl_fixed;
     for (int i = 0; i < nl; i++) {
         const rt355_light &l = shader->lights[i];
         if (l.type < 0 || l.type > 3) return fail(RT355_ERR_ARG, "light type must be 0..3");
@@ -3273,14 +3328,26 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         hl[i].type = l.type; hl[i].pad_ = 0;
         put3(hl[i].shadow_dir, hnormalize(hmul(H3(l.direction), -1.0)));
     }
-    if (nl > sc->lights_cap) {
-        if (sc->d_lights) { (void)hipFree(sc->d_lights); sc->d_lights = nullptr; sc->lights_cap = 0; }
-        HIP_TRY(hipMalloc((void **)&sc->d_lights, (size_t)nl * sizeof(DLight)));
-        sc->lights_cap = nl;
+    DLight *d_lights = nullptr;
+    if (noalloc) {
+        d_lights = (DLight *)(na + NOALLOC_LIGHTS_AT);
+        for (int first = 0; first < nl; first += LIGHT_PACK) {
+            LightPack pack;
+            const int count = std::min(LIGHT_PACK, nl - first);
+            memcpy(pack.l, hl + first, (size_t)count * sizeof(DLight));
+            hipLaunchKernelGGL(k_put_lights, dim3(1), dim3(64), 0, st, pack, d_lights, first, count);
+        }
+    } else {
+        if (nl > sc->lights_cap) {
+            if (sc->d_lights) { (void)hipFree(sc->d_lights); sc->d_lights = nullptr; sc->lights_cap = 0; }
+            HIP_TRY(hipMalloc((void **)&sc->d_lights, (size_t)nl * sizeof(DLight)));
+            sc->lights_cap = nl;
+        }
+        if (nl) HIP_TRY(hipMemcpyAsync(sc->d_lights, hl, (size_t)nl * sizeof(DLight), hipMemcpyHostToDevice, st));
+        d_lights = sc->d_lights;
     }
-    if (nl) HIP_TRY(hipMemcpyAsync(sc->d_lights, hl.data(), (size_t)nl * sizeof(DLight), hipMemcpyHostToDevice, st));
     ShaderView sh;
-    sh.lights = sc->d_lights; sh.n_lights = nl;
+    sh.lights = d_lights; sh.n_lights = nl;
     sh.ambient = pack_rgb(shader->ambient); sh.specular = pack_rgb(shader->specular); sh.border = pack_rgb(shader->border);
     DCamera dc = set_camera(cam);
 
@@ -3319,7 +3386,13 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         for (int k = 0; k < nl; k++)
             if (bundles[1 + k].kind) bundles[1 + k].binned = 1;
 
-    const Work &w = sc->work;
+    Work w_noalloc{};
+    if (noalloc) {
+        w_noalloc.counters = (unsigned long long *)na;
+        w_noalloc.rec_sum = (uint32_t *)(na + NOALLOC_SUB_AT);
+        w_noalloc.n = f.n_rays;
+    }
+    const Work &w = noalloc ? w_noalloc : sc->work;
     HIP_TRY(hipEventRecord(sc->ev_begin, st));
     HIP_TRY(hipMemsetAsync(w.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
     const unsigned per_ray_blocks = (f.n_rays + 255) / 256;
@@ -3604,7 +3677,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
 
 extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                                    const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
-    return render_enqueue(sc, cam, shader, opts, d_pixmap, hip_stream, stats);
+    return render_enqueue(sc, cam, shader, opts, d_pixmap, hip_stream, stats, false);
+}
+extern "C" int rt355_render_device_noalloc(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
+                                           const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
+    return render_enqueue(sc, cam, shader, opts, d_pixmap, hip_stream, stats, true);
 }
 
 extern "C" int rt355_scene_sync(rt355_scene *sc) {
@@ -3800,7 +3877,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         part.row_begin = part_y0[i]; part.row_end = part_y0[i + 1];
         rt355_stats st;
         memset(&st, 0, sizeof st);
-        rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, &st);
+        rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, &st, false);
         if (rc == RT355_OK && !pinned && i > 0) { // meanwhile: the part before this one, from staging to the pixmap
             hipError_t e = hipEventSynchronize(sc->ev_copy[i - 1]);
             if (e != hipSuccess) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));

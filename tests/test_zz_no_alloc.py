@@ -1,0 +1,117 @@
+"""GPU: rt355_render_device_noalloc, the entry point for callers that cannot allocate, against
+rt355_render_device through the C ABI: the same bytes and the same ray counts, on two calls in a row (the
+second with a smaller input: both share the one static array of the GPU, which keeps the first call's
+contents), supersampled frames (the sub-sample colours live in that array), every unsearched renderer, and
+the limits it refuses beyond."""
+import numpy as np
+import pytest
+
+from raytracer_amd import binding as B
+from raytracer_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    from raytracer_amd import api as A
+    A.lib()
+    return A
+
+
+def _both(api, r, cam, sh, o):
+    """One frame through each entry point: (frame, stats) of rt355_render_device and of the no-alloc one."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    out = []
+    for call in (r.render_device, r.render_device_noalloc):
+        fb = torch.full((o.height, o.width, 3), 77, dtype=torch.uint8, device="cuda")
+        call(cam, sh, o, fb.data_ptr(), stream)
+        st = r.sync()
+        out.append((fb.cpu().numpy(), st))
+    return out
+
+
+KEYS = ("primary_rays", "shadow_rays", "primary_hits", "secondary_rays", "gather_rays", "exact_tests")
+
+
+def test_noalloc_equals_render_device_two_calls_in_a_row(api):
+    sc, sh, _, _, _ = S.small_case("default_2lights")
+    r = api.Renderer(sc)
+    # first call: supersampled 320x200 (256 000 sub-sample colours in the array); second: a smaller plain frame
+    for (w, h, alias) in ((320, 200, 2), (96, 64, 0), (64, 48, 3)):
+        cam = S.default_camera(w, h)
+        (want, wst), (got, gst) = _both(api, r, cam, sh, B.opts(w, h, alias=alias, seed=11))
+        assert np.array_equal(got, want), (w, h, alias)
+        for k in KEYS:
+            assert gst[k] == wst[k], (k, w, h, alias)
+        assert gst["primary_rays"] == w * h * max(1, alias) ** 2
+    r.close()
+
+
+@pytest.mark.parametrize("name", ["mirrors", "glass", "quadrics", "environment", "textured", "no_lights", "empty_scene"])
+def test_noalloc_every_unsearched_renderer(api, name):
+    sc, sh, cam, w, h = S.small_case(name)
+    r = api.Renderer(sc)
+    (want, wst), (got, gst) = _both(api, r, cam, sh, B.opts(w, h))
+    assert np.array_equal(got, want)
+    for k in KEYS:
+        assert gst[k] == wst[k], k
+    # slabs and tile shares through the no-alloc call
+    import torch
+    fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    for g in range(3):
+        r.render_device_noalloc(cam, sh, B.opts(w, h, tile_rows=8, tile_count=3, tile_phase=g), fb.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        r.sync()
+    assert np.array_equal(fb.cpu().numpy(), want)
+    r.close()
+
+
+def test_noalloc_gather_and_brute_mode_of_a_larger_scene(api):
+    dirs = B.geodesic(B.icosphere(1))
+    sc, sh, cam, w, h = S.small_case("default_2lights")
+    r = api.Renderer(sc)
+    r.set_directions(dirs)
+    for shading in (B.SHADING_BLEED, B.SHADING_OCCLUSION):
+        (want, wst), (got, gst) = _both(api, r, cam, sh, B.opts(w, h, alias=2, seed=5, shading=shading))
+        assert np.array_equal(got, want) and gst["gather_rays"] == wst["gather_rays"] > 0
+    r.close()
+    # 300 spheres: searched by default (refused), rendered without a search in mode BRUTE
+    sc, sh, cam, w, h = S.small_case("spheres300")
+    r = api.Renderer(sc)
+    (want, wst), (got, gst) = _both(api, r, cam, sh, B.opts(w, h, mode=B.MODE_BRUTE))
+    assert np.array_equal(got, want) and gst["shadow_rays"] == wst["shadow_rays"]
+    import torch
+    fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(api.Rt355Error, match="UNSUPPORTED.*searched"):
+        r.render_device_noalloc(cam, sh, B.opts(w, h), fb.data_ptr(), 0)
+    r.close()
+
+
+def test_noalloc_limits(api):
+    import torch
+    sc = S.default_scene()
+    r = api.Renderer(sc)
+    fb = torch.zeros((2160, 3840, 3), dtype=torch.uint8, device="cuda")
+    cam = S.default_camera(3840, 2160)
+    with pytest.raises(api.Rt355Error, match="UNSUPPORTED.*sub-samples"):   # 33 M sub-samples in one call
+        r.render_device_noalloc(cam, S.default_shader(1), B.opts(3840, 2160, alias=2), fb.data_ptr(), 0)
+    # ... in row slabs it fits: 256 rows x 3840 x 4 sub-samples < 2^22
+    want = torch.zeros_like(fb)
+    r.render_device(cam, S.default_shader(1), B.opts(3840, 2160, alias=2, seed=1, row_begin=512, row_end=768), want.data_ptr(), 0)
+    r.sync()
+    r.render_device_noalloc(cam, S.default_shader(1), B.opts(3840, 2160, alias=2, seed=1, row_begin=512, row_end=768), fb.data_ptr(), 0)
+    r.sync()
+    assert torch.equal(fb, want) and bool(fb[512:768].any())
+    many = S.Shader(S.ring_lights(65), 0x101010, 0xDDDDDD, 0x000000)
+    with pytest.raises(api.Rt355Error, match="UNSUPPORTED.*lights"):
+        r.render_device_noalloc(S.default_camera(64, 48), many, B.opts(64, 48), fb.data_ptr(), 0)
+    # 64 lights (four packs of 16) are within the limit
+    most = S.Shader(S.ring_lights(64), 0x101010, 0xDDDDDD, 0x000000)
+    (want, wst), (got, gst) = _both(api, r, S.default_camera(64, 48), most, B.opts(64, 48))
+    assert np.array_equal(got, want) and gst["shadow_rays"] == wst["shadow_rays"] > 0
+    r.close()
