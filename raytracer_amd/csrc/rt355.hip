@@ -133,6 +133,10 @@ struct Frame {
     // is cut into tiles of tile_rows rows and this call renders tiles tile_phase, tile_phase + tile_count, ...;
     // `rows` then counts the rows of those tiles only.  tile_count <= 1: the slab as a whole.
     int32_t tile_rows, tile_count, tile_phase;
+    // Searched frames keep every ray's colour in Work::rec_sum and k_average writes the pixmap in whole rows
+    // (the rays of a wave are a 16 x 16 block of every other pixel: their own byte stores leave every line of the
+    // pixmap half written by workgroups that run on other XCDs).
+    int32_t deferred;
 };
 // row of the frame that local row `y` of the call is (local rows are the rows rendered, in order)
 __device__ __forceinline__ int frame_row(const Frame &f, int y) {
@@ -1600,25 +1604,73 @@ __device__ __forceinline__ int nearest_occluder_wave(const SceneView &s, const R
 __device__ __forceinline__ void store_pixel(unsigned char *__restrict__ pixmap, const Frame &f, const Work &w,
                                             uint32_t rid, int x, int y, uint32_t clr) {
     if (f.level >= 0) { w.lvl_clr[(size_t)f.level * w.n + rid] = clr; return; }
-    if (f.alias > 0) { w.rec_sum[rid] = clr; return; }
+    if (f.alias > 0 || f.deferred) { w.rec_sum[rid] = clr; return; }
     size_t i = ((size_t)frame_row(f, y) * (size_t)f.width + (size_t)x) * 3;
     pixmap[i] = (unsigned char)cr(clr); pixmap[i + 1] = (unsigned char)cg(clr); pixmap[i + 2] = (unsigned char)cb(clr);
 }
+// SEG neighbouring pixels of one row, one per lane in SEG consecutive lanes (SEG = 32: each half of the wave has a
+// row of its own; SEG = 64: the whole wave), stored as 3 SEG / 4 whole dwords: lane l of the segment builds dword l
+// from the colours of pixels a = 4 l / 3 and a + 1, which it takes from their lanes.  A segment that is not whole
+// (the frame's right edge, a row past the slab) or not dword-aligned (a width that is no multiple of 4) falls back
+// to byte stores.  Called by all lanes of the wave; `valid`: this lane has a pixel.
+template <int SEG>
+__device__ __forceinline__ void store_row_segment(unsigned char *__restrict__ pixmap, const Frame &f, int x, int y,
+                                                  bool valid, uint32_t clr) {
+    const int lane = threadIdx.x & 63, l = lane & (SEG - 1), first = lane - l;
+    const int a = (4 * l) / 3, shift = 8 * (4 * l - 3 * a);
+    const uint32_t ca = (uint32_t)__shfl((int)clr, first + min(a, SEG - 1), 64);
+    const uint32_t cb_ = (uint32_t)__shfl((int)clr, first + min(a + 1, SEG - 1), 64);
+    const unsigned long long have = __ballot(valid);
+    const unsigned long long mine = (SEG == 64) ? ~0ull : (0xffffffffull << first);
+    if (!valid) return;
+    unsigned char *at = pixmap + ((size_t)frame_row(f, y) * (size_t)f.width + (size_t)(x - l)) * 3; // the segment's first byte
+    if ((have & mine) == mine && ((uintptr_t)at & 3u) == 0) {
+        if (l < 3 * SEG / 4)
+            ((uint32_t *)at)[l] = (uint32_t)(((unsigned long long)(ca & 0xffffffu) | ((unsigned long long)(cb_ & 0xffffffu) << 24)) >> shift);
+    } else {
+        at += 3 * l;
+        at[0] = (unsigned char)cr(clr); at[1] = (unsigned char)cg(clr); at[2] = (unsigned char)cb(clr);
+    }
+}
+// The one-kernel renderers (a thread does the whole pixel) number their grid points so that a workgroup owns whole
+// lines of the pixmap: 256 neighbouring grid points of one row per workgroup (768 contiguous bytes), 64 per wave.
+#define DIRECT_SEG 64
+__device__ __forceinline__ void direct_xy(const Frame &f, int *x, int *y) {
+    const uint32_t across = (uint32_t)(f.grid_w + 255) / 256u;
+    *x = (int)((blockIdx.x % across) * 256u + threadIdx.x);
+    *y = (int)(blockIdx.x / across);
+}
+// ... and what they do with the colour: a sub-sample goes to k_average's array, a pixel to the pixmap
+__device__ __forceinline__ void direct_store(unsigned char *__restrict__ pixmap, const Frame &f, const Work &w, int x, int y,
+                                             bool valid, uint32_t clr) {
+    if (f.alias > 0) { // uniform
+        if (valid) w.rec_sum[xy_to_rid(x, y, f.tiles_x)] = clr;
+        return;
+    }
+    store_row_segment<DIRECT_SEG>(pixmap, f, x, y, valid, clr);
+}
 // CalcPixel's average over the alias x alias sub-samples of a pixel (main.cpp:315-325): sums of the
 // sub-samples' 8-bit channels in double, divided by alias * alias, truncated by Color's constructor
+// (alias == 0: the one colour of the pixel as a searched frame left it in the array.)  A wave takes 64 neighbouring
+// pixels of a row and writes them as 48 dwords.
 __global__ __launch_bounds__(256) void k_average(Frame f, const uint32_t *__restrict__ sub,
                                                  unsigned char *__restrict__ pixmap) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= f.width || y >= f.rows) return;
-    double red = 0, green = 0, blue = 0;
-    for (int q = 0; q < f.alias; q++)
-        for (int p = 0; p < f.alias; p++) {
-            const uint32_t clr = sub[xy_to_rid(x * f.alias + p, y * f.alias + q, f.tiles_x)];
-            red += (double)(int)cr(clr); green += (double)(int)cg(clr); blue += (double)(int)cb(clr);
-        }
-    const double n = (double)(f.alias * f.alias);
-    const size_t i = ((size_t)frame_row(f, y) * (size_t)f.width + (size_t)x) * 3;
-    pixmap[i] = (unsigned char)q8(red / n); pixmap[i + 1] = (unsigned char)q8(green / n); pixmap[i + 2] = (unsigned char)q8(blue / n);
+    const bool valid = x < f.width && y < f.rows;
+    uint32_t out = 0u;
+    if (valid && f.alias <= 0) {
+        out = sub[xy_to_rid(x, y, f.tiles_x)];
+    } else if (valid) {
+        double red = 0, green = 0, blue = 0;
+        for (int q = 0; q < f.alias; q++)
+            for (int p = 0; p < f.alias; p++) {
+                const uint32_t clr = sub[xy_to_rid(x * f.alias + p, y * f.alias + q, f.tiles_x)];
+                red += (double)(int)cr(clr); green += (double)(int)cg(clr); blue += (double)(int)cb(clr);
+            }
+        const double n = (double)(f.alias * f.alias);
+        out = RGB(q8(red / n), q8(green / n), q8(blue / n));
+    }
+    store_row_segment<64>(pixmap, f, x, y, valid, out);
 }
 
 // Shadow rays of one group of lights for a primary hit (shader.h:395-404): the fp32 search record of
@@ -1773,13 +1825,14 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
 template <bool REFLECT, bool ENV>
 __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                        unsigned char *__restrict__ pixmap) {
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rid = 0; // (no per-ray lists on this path)
     uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0;
-    do {
-    if (rid >= f.n_rays) break;
     int x, y;
-    rid_to_xy(rid, f.tiles_x, &x, &y);
-    if (!(x < f.grid_w && y < f.grid_h)) break;
+    direct_xy(f, &x, &y);
+    const bool valid = x < f.grid_w && y < f.grid_h;
+    uint32_t pixel = 0u;
+    do {
+    if (!valid) break;
     Ray e = grid_ray(cam, f, x, y);
     Spill none; none.pool = nullptr; none.count = nullptr;
     constexpr int LEVELS = REFLECT ? 4 : 1;
@@ -1828,8 +1881,9 @@ __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneVie
         if (level == deepest) clr = level_clr[level];
         else if (level < deepest) clr = cadd(cmul(level_clr[level], 1 - level_ks[level]), cmul(clr, level_ks[level]));
     }
-    store_pixel(pixmap, f, w, rid, x, y, clr);
+    pixel = clr;
     } while (0);
+    direct_store(pixmap, f, w, x, y, valid, pixel);
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
@@ -1916,13 +1970,14 @@ __device__ __forceinline__ void intersect_inside(const SceneView &s, int obj, co
 // (three waves per SIMD: at the two the compiler picks by itself the frame takes 30 % longer, at four the spills cost more)
 __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                         unsigned char *__restrict__ pixmap) {
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rid = 0; // (no per-ray lists on this path)
     uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0, n_deep = 0;
-    do {
-    if (rid >= f.n_rays) break;
     int x, y;
-    rid_to_xy(rid, f.tiles_x, &x, &y);
-    if (!(x < f.grid_w && y < f.grid_h)) break;
+    direct_xy(f, &x, &y);
+    const bool valid = x < f.grid_w && y < f.grid_h;
+    uint32_t pixel = 0u;
+    do {
+    if (!valid) break;
     Ray e = grid_ray(cam, f, x, y);
     Spill none; none.pool = nullptr; none.count = nullptr;
     uint32_t op_clr[REFRACT_OPS], op_what[REFRACT_OPS]; // what = object | kind << 30
@@ -2037,8 +2092,9 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
         }
         if (!resumed) break;
     }
-    store_pixel(pixmap, f, w, rid, x, y, value);
+    pixel = value;
     } while (0);
+    direct_store(pixmap, f, w, x, y, valid, pixel);
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
@@ -2064,13 +2120,14 @@ struct Gather { const double *dirs; int32_t n; };
 template <bool BLEED, int FEW>
 __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                        Gather ga, unsigned char *__restrict__ pixmap) {
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rid = 0; // (no per-ray lists on this path)
     uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_gather = 0;
-    do {
-    if (rid >= f.n_rays) break;
     int x, y;
-    rid_to_xy(rid, f.tiles_x, &x, &y);
-    if (!(x < f.grid_w && y < f.grid_h)) break;
+    direct_xy(f, &x, &y);
+    const bool valid = x < f.grid_w && y < f.grid_h;
+    uint32_t pixel = 0u;
+    do {
+    if (!valid) break;
     const Ray e = grid_ray(cam, f, x, y);
     Spill none; none.pool = nullptr; none.count = nullptr;
     Closest c;
@@ -2207,8 +2264,9 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
         }
         clr = cadd(cmul(cm0, 1 - part), cmul(other, part));
     }
-    store_pixel(pixmap, f, w, rid, x, y, clr);
+    pixel = clr;
     } while (0);
+    direct_store(pixmap, f, w, x, y, valid, pixel);
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 1, n_eval);
     wave_count(w.counters, 7, n_gather);
@@ -2682,7 +2740,7 @@ struct rt355_scene {
     unsigned char *fb = nullptr; size_t fb_bytes = 0;
     unsigned char *stage = nullptr; size_t stage_bytes = 0;
     hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> ev_copy;
+    std::vector<hipEvent_t> ev_copy, ev_part; // per part of a frame: its rows have arrived / have been rendered
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
     uint64_t pending_primary = 0, pending_pairs_static = 0;
@@ -3104,6 +3162,7 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (sc->fb) (void)hipFree(sc->fb);
     if (sc->stage) (void)hipHostFree(sc->stage);
     for (hipEvent_t e : sc->ev_copy) (void)hipEventDestroy(e);
+    for (hipEvent_t e : sc->ev_part) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->ev_search) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->ev_resolve) (void)hipEventDestroy(e);
     delete sc;
@@ -3239,10 +3298,15 @@ static int ensure_levels(rt355_scene *sc) {
     return fail(RT355_ERR_DEVICE, std::string("level arrays: ") + hipGetErrorString(e));
 }
 
+// A frame that one kernel renders can be enqueued as several calls, one per group of rows, that count into the
+// same statistics and are waited for as one: `first` clears the counters and uploads the lights, `last` closes
+// the frame (rt355_render reads every part back while the next one renders).
+struct PartOfFrame { bool first, last; };
 // One frame (or slab) enqueued on `hip_stream`.  noalloc: the entry point that allocates nothing -- the counters,
 // the lights and the sub-sample colours live in the static array, and frames that need the workspace are refused.
 static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
-                          const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats, bool noalloc) {
+                          const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats, bool noalloc,
+                          PartOfFrame part = PartOfFrame{true, true}) {
     if (!sc || !cam || !shader || !opts || !d_pixmap) return fail(RT355_ERR_ARG, "rt355_render_device: null argument");
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
     if (opts->alias < 0 || opts->alias > 64) return fail(RT355_ERR_ARG, "alias must be 0..64");
@@ -3257,7 +3321,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     HIP_TRY(hipSetDevice(sc->device));
     if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     hipStream_t st = (hipStream_t)hip_stream;
-    if (rows.count == 0) { // a share without tiles (more shares than the slab has tiles): nothing to render
+    if (rows.count == 0 && part.first && part.last) { // a share without tiles (more shares than the slab has tiles): nothing to render
         if (stats) memset(stats, 0, sizeof *stats);
         return RT355_OK;
     }
@@ -3276,6 +3340,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     f.tiles_x = (f.grid_w + TILE_W - 1) / TILE_W; f.tiles_y = (f.grid_h + TILE_H - 1) / TILE_H;
     f.n_rays = (uint32_t)n_rays64;
     f.level = -1;
+    f.deferred = 0;
     const int nl = shader->n_lights;
     const int slots = slots_for(f.n_rays, nl);
     const int n_groups = (nl + slots - 1) / slots;
@@ -3293,6 +3358,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     }
     const bool levels = extra_levels > 0;
     const bool gather_searched = can_search && opts->shading != RT355_SHADING_LIGHTS;
+    f.deferred = can_search ? 1 : 0;
     int rc = RT355_OK;
     unsigned char *na = nullptr; // the no-alloc array of this device
     if (noalloc) {
@@ -3331,7 +3397,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     DLight *d_lights = nullptr;
     if (noalloc) {
         d_lights = (DLight *)(na + NOALLOC_LIGHTS_AT);
-        for (int first = 0; first < nl; first += LIGHT_PACK) {
+        for (int first = 0; first < nl && part.first; first += LIGHT_PACK) {
             LightPack pack;
             const int count = std::min(LIGHT_PACK, nl - first);
             memcpy(pack.l, hl + first, (size_t)count * sizeof(DLight));
@@ -3343,7 +3409,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             HIP_TRY(hipMalloc((void **)&sc->d_lights, (size_t)nl * sizeof(DLight)));
             sc->lights_cap = nl;
         }
-        if (nl) HIP_TRY(hipMemcpyAsync(sc->d_lights, hl, (size_t)nl * sizeof(DLight), hipMemcpyHostToDevice, st));
+        if (nl && part.first) HIP_TRY(hipMemcpyAsync(sc->d_lights, hl, (size_t)nl * sizeof(DLight), hipMemcpyHostToDevice, st));
         d_lights = sc->d_lights;
     }
     ShaderView sh;
@@ -3393,9 +3459,15 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         w_noalloc.n = f.n_rays;
     }
     const Work &w = noalloc ? w_noalloc : sc->work;
-    HIP_TRY(hipEventRecord(sc->ev_begin, st));
-    HIP_TRY(hipMemsetAsync(w.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
+    if (part.first) {
+        HIP_TRY(hipEventRecord(sc->ev_begin, st));
+        HIP_TRY(hipMemsetAsync(w.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
+        sc->pending_primary = 0;
+    }
+    if (!(part.first && part.last) && can_search)
+        return fail(RT355_ERR_ARG, "internal: only a frame that one kernel renders is enqueued in parts");
     const unsigned per_ray_blocks = (f.n_rays + 255) / 256;
+    const unsigned direct_blocks = (unsigned)((f.grid_w + 255) / 256) * (unsigned)f.grid_h; // see direct_xy
     const unsigned table_blocks = (unsigned)(sc->n_table / 256);            // one thread per table row
     const unsigned top_blocks = (unsigned)(sc->tables.top_stride * 64 / 256); // one thread per chunk, padding included
     const unsigned n_tiles = (unsigned)(f.tiles_x * f.tiles_y);
@@ -3511,28 +3583,28 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         return RT355_OK;
     };
     if (!can_search) { // nothing to search: the whole pixel in one kernel
-        HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
+        if (part.first) HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
         const Gather ga{sc->d_dirs, sc->n_dirs};
         const SceneView &v = sc->view;
         const bool few = v.n_planes <= GATHER_FEW && v.n_spheres <= GATHER_FEW && v.n_planes + v.n_spheres == v.n_prims &&
                          !getenv("RT355_GATHER_GENERAL");
-#define LAUNCH_GATHER(B, F) hipLaunchKernelGGL((k_render_gather<B, F>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix)
+#define LAUNCH_GATHER(B, F) hipLaunchKernelGGL((k_render_gather<B, F>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix)
         if (opts->shading == RT355_SHADING_BLEED) {
             if (few) LAUNCH_GATHER(true, GATHER_FEW); else LAUNCH_GATHER(true, 0);
         } else if (opts->shading == RT355_SHADING_OCCLUSION) {
             if (few) LAUNCH_GATHER(false, GATHER_FEW); else LAUNCH_GATHER(false, 0);
         }
 #undef LAUNCH_GATHER
-#define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
+#define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
         else if (refract) {
-            hipLaunchKernelGGL(k_render_refract, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+            hipLaunchKernelGGL(k_render_refract, dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
         } else if (sc->reflective) {
             if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(true, true); else LAUNCH_DIRECT(true, false);
         } else {
             if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(false, true); else LAUNCH_DIRECT(false, false);
         }
 #undef LAUNCH_DIRECT
-        HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
+        if (part.last) HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
     }
     int resolves = 0;
     // one level of the frame: the search of its rays (camera rays: the eye's tables; mirror rays: the scene table),
@@ -3658,9 +3730,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         }
         if (levels) hipLaunchKernelGGL(k_fold_levels, dim3(per_ray_blocks), dim3(256), 0, st, f, w, pix);
     }
-    if (f.alias > 0)
+    if (f.alias > 0 || f.deferred)
         hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
     HIP_TRY(hipGetLastError());
+    sc->pending_primary += (uint64_t)f.grid_w * (uint64_t)f.grid_h;
+    if (!part.last) return RT355_OK;
     HIP_TRY(hipEventRecord(sc->ev_end, st));
     HIP_TRY(hipMemcpyAsync(sc->host_counters, w.counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
@@ -3668,7 +3742,6 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     sc->pending = true;
     sc->pending_stats = stats;
     sc->pending_stream = st;
-    sc->pending_primary = (uint64_t)f.grid_w * (uint64_t)f.grid_h;
     sc->pending_nprims = sc->view.n_prims;
     sc->search_launches = launches;
     sc->resolve_launches = can_search ? resolves : 1;
@@ -3783,7 +3856,9 @@ extern "C" int rt355_scene_search_launch_ms(rt355_scene *sc, int32_t index, doub
 // Page-locked host memory for the pixmap of rt355_render.
 extern "C" void *rt355_host_alloc(uint64_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+    unsigned flags = hipHostMallocDefault;
+    if (const char *e = getenv("RT355_HOST_ALLOC_FLAGS")) flags = (unsigned)strtoul(e, nullptr, 0); // (experiments)
+    if (hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), flags) != hipSuccess) {
         (void)hipGetLastError();
         g_err = "rt355_host_alloc: hipHostMalloc failed";
         return nullptr;
@@ -3822,8 +3897,26 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         sc->ev_copy.push_back(e);
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sc->ev_part.push_back(e);
     }
     const bool pinned = host_is_pinned(pixmap);
+    if (pinned && !getenv("RT355_READBACK_COPY")) {
+        // A page-locked pixmap is mapped into the device's address space: the kernels that write the pixels write
+        // them there, whole dwords in row order, and the transfer over PCIe runs while the frame is rendered --
+        // no readback step is left.  Measured on MI355X at 3840x2160: k_average streams a searched frame's pixels
+        // out at the 55 GB/s the copy engine reaches; a one-kernel frame's own stores reach 40 GB/s, which beats
+        // rendering and copying in parts as soon as the kernel runs longer than the transfer (glass room 1.02
+        // against 1.19 ms, mirrors 1.23 against 1.33, the default scene 0.63 against 0.61).  The event the call
+        // waits on orders the writes before the caller's reads.  (RT355_READBACK_COPY selects the copy.)
+        void *mapped = nullptr;
+        if (hipHostGetDevicePointer(&mapped, pixmap, 0) == hipSuccess && mapped) {
+            int rc = render_enqueue(sc, cam, shader, opts, mapped, nullptr, stats, false);
+            if (rc == RT355_OK) rc = rt355_scene_sync(sc);
+            return rc;
+        }
+        (void)hipGetLastError();
+    }
     if (!pinned && bytes > sc->stage_bytes) {
         if (sc->stage) { (void)hipHostFree(sc->stage); sc->stage = nullptr; sc->stage_bytes = 0; }
         HIP_TRY(hipHostMalloc((void **)&sc->stage, bytes, hipHostMallocDefault));
@@ -3831,15 +3924,15 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     }
     // parts: whole multiples of 32 rows (the tile height of the ray numbering divides it), at least 256 rows each;
     // a call that renders a share of interleaved row tiles is one part
+    // a searched frame is a chain of a dozen launches whose cost does not shrink with the rows: one part
     int n_parts = 1;
-    const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS;
-    if (opts->tile_count <= 1) {
-        n_parts = searched ? 2 : 4;
+    const bool refract = sc->refractive && opts->shading == RT355_SHADING_LIGHTS;
+    const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
+    if (opts->tile_count <= 1 && !searched) {
+        n_parts = 6;
         if (const char *e = getenv("RT355_RENDER_PARTS")) n_parts = atoi(e);
-        n_parts = std::max(1, std::min(n_parts, std::min(RENDER_PARTS_MAX, (rows.y1 - rows.y0) / 256)));
+        n_parts = std::max(1, std::min(n_parts, std::min(RENDER_PARTS_MAX, (rows.y1 - rows.y0) / 128)));
     }
-    rt355_stats total;
-    memset(&total, 0, sizeof total);
     int part_y0[RENDER_PARTS_MAX + 1];
     for (int i = 0; i <= n_parts; i++) {
         part_y0[i] = rows.y0 + (int)((int64_t)(rows.y1 - rows.y0) * i / n_parts) / 32 * 32;
@@ -3847,8 +3940,10 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         if (i == n_parts) part_y0[i] = rows.y1;
     }
     unsigned char *host_dst = pinned ? pixmap : sc->stage;
-    // the rows a part (or a share's tile) covers go back as one transfer each
-    auto read_back = [&](int ya, int yb, hipEvent_t done) -> int {
+    // the rows a part (or a share's tiles) covers go back as one transfer each, once the part has been rendered
+    auto read_back = [&](int ya, int yb, hipEvent_t rendered, hipEvent_t done) -> int {
+        HIP_TRY(hipEventRecord(rendered, nullptr));
+        HIP_TRY(hipStreamWaitEvent(sc->copy_stream, rendered, 0));
         if (opts->tile_count > 1) {
             for (int k = opts->tile_phase; k * opts->tile_rows < yb - ya; k += opts->tile_count) {
                 const int ta = ya + k * opts->tile_rows, tb = std::min(yb, ta + opts->tile_rows);
@@ -3870,33 +3965,29 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
             memcpy(pixmap + ya * row_bytes, sc->stage + ya * row_bytes, (size_t)(yb - ya) * row_bytes);
         }
     };
+    // Every part is enqueued at once -- they count into the same statistics -- and each is read back, on the second
+    // stream, as soon as its kernel has finished, while the later parts render.
     int rc = RT355_OK;
-    int copies_in_flight = 0; // parts whose transfer was enqueued
+    int n_copies = 0; // parts whose transfer was enqueued
     for (int i = 0; i < n_parts && rc == RT355_OK; i++) {
         rt355_opts part = *opts;
         part.row_begin = part_y0[i]; part.row_end = part_y0[i + 1];
-        rt355_stats st;
-        memset(&st, 0, sizeof st);
-        rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, &st, false);
-        if (rc == RT355_OK && !pinned && i > 0) { // meanwhile: the part before this one, from staging to the pixmap
-            hipError_t e = hipEventSynchronize(sc->ev_copy[i - 1]);
-            if (e != hipSuccess) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
-            else to_pixmap(part_y0[i - 1], part_y0[i]);
-        }
-        if (rc == RT355_OK) rc = rt355_scene_sync(sc);
-        if (rc != RT355_OK) break;
-        total.primary_rays += st.primary_rays; total.shadow_rays += st.shadow_rays; total.pair_tests += st.pair_tests;
-        total.exact_tests += st.exact_tests; total.overflow_rays += st.overflow_rays; total.ms_device += st.ms_device;
-        total.packet_survivors += st.packet_survivors; total.primary_hits += st.primary_hits;
-        total.secondary_rays += st.secondary_rays; total.gather_rays += st.gather_rays;
-        rc = read_back(part_y0[i], part_y0[i + 1], sc->ev_copy[i]);
-        if (rc == RT355_OK) copies_in_flight = i + 1;
+        rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, stats, false, PartOfFrame{i == 0, i == n_parts - 1});
+        if (rc == RT355_OK) rc = read_back(part_y0[i], part_y0[i + 1], sc->ev_part[i], sc->ev_copy[i]);
+        if (rc == RT355_OK) n_copies = i + 1;
+    }
+    for (int i = 0; i < n_copies && rc == RT355_OK && !pinned; i++) { // staged parts -> the pixmap, each as it arrives
+        hipError_t e = hipEventSynchronize(sc->ev_copy[i]);
+        if (e != hipSuccess) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
+        else to_pixmap(part_y0[i], part_y0[i + 1]);
     }
     // (on an error too: no transfer into the caller's memory may outlive the call)
     hipError_t e = hipStreamSynchronize(sc->copy_stream);
     if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
-    if (rc == RT355_OK && !pinned && copies_in_flight == n_parts) to_pixmap(part_y0[n_parts - 1], part_y0[n_parts]);
-    if (rc == RT355_OK && stats) *stats = total;
+    if (sc->pending) { // the frame's statistics, and what its kernels reported
+        const int rc_sync = rt355_scene_sync(sc);
+        if (rc == RT355_OK) rc = rc_sync;
+    }
     return rc;
 }
 

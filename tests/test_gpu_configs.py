@@ -173,25 +173,31 @@ def test_interleaved_row_tiles_small(api, oracle):
 
 
 def test_host_pixmap_paths_agree(api):
-    """rt355_render into a pageable pixmap (staged), into a page-locked one (direct), in one part and in several
-    (RT355_RENDER_PARTS), and rt355_render_device: the same bytes and ray counts; a second, smaller frame on the
+    """rt355_render into a pageable pixmap (rendered in HBM, read back through staging), into a page-locked one
+    (written by the kernels themselves, or read back by copy), in one part and in several, a searched scene and
+    an unsearched one, and rt355_render_device: the same bytes and ray counts; a second, smaller frame on the
     same handle reuses the framebuffer."""
     import os
-    sc, sh, cam, _, _ = S.small_case("spheres300")
-    r = api.Renderer(sc)
-    for w, h in ((640, 1100), (320, 300)):
-        cam = S.default_camera(w, h)
-        dev, dst = _device_frame(api, r, cam, sh, B.opts(w, h), w, h)
-        for parts in ("1", "3", "8"):
-            os.environ["RT355_RENDER_PARTS"] = parts
-            try:
-                pageable, pst = r.render(cam, sh, w, h)
-                host = api.HostPixmap(w, h)
-                _, hst = r.render(cam, sh, w, h, out=host.array)
-            finally:
-                del os.environ["RT355_RENDER_PARTS"]
-            assert np.array_equal(pageable, dev) and np.array_equal(host.array, dev), parts
-            for k in ("primary_rays", "shadow_rays", "primary_hits", "exact_tests"):
-                assert pst[k] == hst[k] == dst[k], (parts, k)
+    for case in ("spheres300", "default_2lights"):
+        sc, sh, cam, _, _ = S.small_case(case)
+        r = api.Renderer(sc)
+        for w, h in ((640, 1100), (322, 300)):
+            cam = S.default_camera(w, h)
+            dev, dst = _device_frame(api, r, cam, sh, B.opts(w, h), w, h)
+            host = api.HostPixmap(w, h)
+            _, hst = r.render(cam, sh, w, h, out=host.array)   # the kernels write into the mapped pixmap
+            assert np.array_equal(host.array, dev)
+            for parts in ("1", "3", "8"):
+                os.environ["RT355_RENDER_PARTS"] = parts
+                os.environ["RT355_READBACK_COPY"] = "1"         # ... or into HBM, and the copy engine reads back
+                try:
+                    pageable, pst = r.render(cam, sh, w, h)
+                    host.array[:] = 0
+                    _, cst = r.render(cam, sh, w, h, out=host.array)
+                finally:
+                    del os.environ["RT355_RENDER_PARTS"], os.environ["RT355_READBACK_COPY"]
+                assert np.array_equal(pageable, dev) and np.array_equal(host.array, dev), parts
+                for k in ("primary_rays", "shadow_rays", "primary_hits", "exact_tests"):
+                    assert pst[k] == hst[k] == cst[k] == dst[k], (parts, k)
             host.close()
-    r.close()
+        r.close()

@@ -1,0 +1,45 @@
+"""GPU box: ms per frame of rt355_render (page-locked pixmap) with the pixels written straight into the mapped pixmap
+("direct", the default) and with a readback by copy in 1 .. 8 parts (RT355_READBACK_COPY, RT355_RENDER_PARTS), beside
+rt355_render_device ("dev").  Usage: python tools/render_parts.py WORKLOAD..."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from raytracer_amd import binding as B
+from raytracer_amd.api import HostPixmap, Renderer
+
+for name in sys.argv[1:]:
+    scene, sh, cam, w, h = bench.build_workload(name)
+    shading, dirs = bench.gather_of(name)
+    r = Renderer(scene)
+    if dirs is not None:
+        r.set_directions(dirs)
+    host = HostPixmap(w, h)
+    fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    line = [name]
+    for parts in ("dev", "direct", "1", "2", "4"):
+        os.environ.pop("RT355_READBACK_COPY", None)
+        if parts not in ("dev", "direct"):
+            os.environ["RT355_READBACK_COPY"] = "1"
+            os.environ["RT355_RENDER_PARTS"] = parts
+        def frame():
+            if parts == "dev":
+                r.render_device(cam, sh, B.opts(w, h, shading=shading), fb.data_ptr(), 0)
+                r.sync()
+            else:
+                r.render(cam, sh, w, h, shading=shading, out=host.array)
+        for _ in range(3):
+            frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            frame()
+        torch.cuda.synchronize()
+        line.append(f"{parts}: {(time.perf_counter() - t0) * 50:.3f}")
+    print("  ".join(line), flush=True)
+    r.close()
+    host.close()
