@@ -107,14 +107,19 @@ typedef struct rt355_camera {
 
 /* light_src (light.h:12-56).  `direction` is the stored, already normalised member
  * (light.h:30); the library does not normalise it again.  Types 0 directional, 1 point,
- * 2 spot (soft spot, shader.h:332,370,426), 3 area (treated as a point light by
- * Shader::shading, shader.h:80-82). */
+ * 2 spot (soft spot, shader.h:332,370,426), 3 area (a point light to Shader::shading and
+ * CalcShadow, shader.h:80-82; its area is what CalcSoftShadow aims at). */
 typedef struct rt355_light {
     double position[3];
     double direction[3];
     double color[3];
     int32_t type;
     int32_t pad_;
+    /* The area of an area light (light.h:19-23,44-54), read by RT355_SHADING_SOFT only, and there of lights[0]
+     * alone (shader.h:441-443).  The constructors of the other types leave n0 = (1,0,0), n1 = (0,1,0),
+     * sx = sy = 1 (light.h:19-23): pass those for them. */
+    double n0[3], n1[3];
+    double sx, sy;
 } rt355_light;
 
 /* Shader (shader.h:25-37): the private light list plus the three public colours. */
@@ -143,6 +148,10 @@ typedef struct rt355_shader {
 #define RT355_SHADING_OCCLUSION 1 /* CalcSubPixel2 (main.cpp:163-209) + Shader::shading2, ambient occlusion
                                      (shader.h:100-140)                                                       */
 #define RT355_SHADING_BLEED     2 /* CalcSubPixel2 + Shader::shading3, colour bleeding (shader.h:143-191)       */
+#define RT355_SHADING_SOFT      3 /* CalcSubPixel + Shader::shading with the line commented out at shader.h:91
+                                     in place of the one at :90: CalcSoftShadow (shader.h:439-483), whose shadow
+                                     ray aims at a point of lights[0]'s area chosen per sub-sample by the strata
+                                     of main.cpp:286-288,307-308 (see rt355x_soft_args below)                  */
 
 typedef struct rt355_opts {
     int32_t width, height; /* the reference's globals (main.cpp:33)                         */
@@ -202,6 +211,36 @@ RT355_INLINE double rt355x_rotation(uint32_t seed, int32_t x, int32_t y, int32_t
     z = rt355x_mix64(z ^ (((uint64_t)(uint32_t)sample << 1) | (uint64_t)(axis & 1)));
     z = rt355x_mix64(z ^ 0x726f74617465ull);
     return (double)(z >> 33) / 2147483647.0;
+}
+
+/* The soft-shadow strata of CalcPixel.  Per pixel the reference draws k0, k1 = (int)(rand() / RAND_MAX * 100)
+ * and r = rand() / RAND_MAX (main.cpp:286-288) and gives sub-sample (p, q) the parameters
+ * m = ((p + k0) % alias + r) / alias, n = ((q + k1) % alias + r) / alias (main.cpp:307-308).  As with the jitter,
+ * the three draws come from the counter-based generator instead (which = 0, 1, 2 for k0, k1, r). */
+RT355_INLINE double rt355x_strata(uint32_t seed, int32_t x, int32_t y, int32_t which) {
+    uint64_t z = rt355x_mix64((uint64_t)seed);
+    z = rt355x_mix64(z ^ (uint64_t)(uint32_t)x);
+    z = rt355x_mix64(z ^ (uint64_t)(uint32_t)y);
+    z = rt355x_mix64(z ^ (uint64_t)(uint32_t)which);
+    z = rt355x_mix64(z ^ 0x737472617461ull);
+    return (double)(z >> 33) / 2147483647.0;
+}
+/* What CalcSubPixel receives for sub-sample (p, q) of pixel (x, y) from the call the reference keeps beside the
+ * one it makes, `CalcSubPixel(eye, sce.objs, shd, 0, 1.0, 1, m, n)` (main.cpp:312), given the signature
+ * `(..., int outside, int object_index = 0, double m = 0, double n = 0)` (main.cpp:42): the seventh argument
+ * lands in object_index, so object_index = (int)m, the function's m is the caller's n, and its n stays 0.
+ * alias == 0 is the call of main.cpp:330, which passes neither: all three are 0.  Rays cast by the recursion
+ * (main.cpp:109,126,138,148) pass neither as well. */
+RT355_INLINE void rt355x_soft_args(uint32_t seed, int32_t x, int32_t y, int32_t p, int32_t q, int32_t alias,
+                                   int32_t *object_index, double *m, double *n) {
+    *object_index = 0; *m = 0; *n = 0;
+    if (alias <= 0) return;
+    const int32_t k0 = (int32_t)(rt355x_strata(seed, x, y, 0) * 100), k1 = (int32_t)(rt355x_strata(seed, x, y, 1) * 100);
+    const double r = rt355x_strata(seed, x, y, 2);
+    const double caller_m = ((p + k0) % alias + r) * 1.0 / alias;   /* main.cpp:307 */
+    const double caller_n = ((q + k1) % alias + r) * 1.0 / alias;   /* main.cpp:308 */
+    *object_index = (int32_t)caller_m;                              /* 0, or 1 when r == 1 in the last stratum */
+    *m = caller_n;
 }
 
 typedef struct rt355_stats {
@@ -295,11 +334,12 @@ int rt355_scene_search_launch_ms(rt355_scene *scene, int32_t index, double *ms);
 const char *rt355_last_error(void);
 int rt355_abi_version(void);
 
-/* rt355x_jitter and rt355x_rotation as exported functions. */
+/* rt355x_jitter, rt355x_rotation and rt355x_strata as exported functions. */
 double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim);
 double rt355_rotation(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t axis);
+double rt355_strata(uint32_t seed, int32_t x, int32_t y, int32_t which);
 
-/* The direction set of the gather shaders: the global `geo` that main.cpp:557 fills from Geodesic()
+/* The direction set of the gather shaders: the global `geo` that main.cpp:639 fills from Geodesic()
  * (main.cpp:408-450: the `v` lines of an OBJ file, centred on their mean and normalised).  xyz holds n
  * directions as the reference holds them after that function; they are copied.  n = 0 clears the set
  * (every hit then comes out black, as 0/0 does in shader.h:137,188). */

@@ -107,6 +107,7 @@ inline std::vector<rt355_light> rt355_lights(const std::vector<light_src *> &lig
         std::memset(&q, 0, sizeof q);
         q.type = l->type;
         put(q.position, l->position); put(q.direction, l->direction); put(q.color, l->color);
+        put(q.n0, l->n0); put(q.n1, l->n1); q.sx = l->sx; q.sy = l->sy; // the area CalcSoftShadow aims at (light.h:19-23)
         out.push_back(q);
     }
     return out;
@@ -122,7 +123,7 @@ inline rt355_shader rt355_shader_of(const Shader &shd, const std::vector<rt355_l
     return s;
 }
 
-// The direction set of the gather shaders: the global `geo` that main.cpp:557 fills with Geodesic().
+// The direction set of the gather shaders: the global `geo` that main.cpp:639 fills with Geodesic().
 inline int rt355_set_directions(rt355_scene *scene, const std::vector<Vector3D> &geo) {
     std::vector<double> xyz;
     xyz.reserve(geo.size() * 3);

@@ -71,6 +71,23 @@ def main():
         np.save(os.path.join(OUT, fn), frame)
         meta["gather_cases"].append({"case": name, "level": level, "shading": shading, "alias": alias, "seed": seed,
                                      "width": w, "height": h, "file": fn, "fnv1a64": f"{B.fnv1a64(frame):016x}"})
+    # 1e. soft shadows: CalcSubPixel with Shader::shading's loop run with the reference's own CalcSoftShadow
+    #     (shader.h:439-483, the call commented out at :91) in place of CalcShadow; the strata of main.cpp:286-288
+    #     from rt355_strata in place of rand()
+    meta["soft_cases"] = []
+    for name, kind, alias in (("default_2lights", "area", 0), ("default_2lights", "area", 2), ("default_2lights", "point", 3),
+                              ("mesh", "area", 2), ("mirrors", "area", 2), ("spheres300", "area", 2), ("glass", "area", 2),
+                              ("textured", "point", 0), ("environment", "area", 1), ("mirrors_mesh", "area", 3)):
+        sc, _, cam, w, h = S.small_case(name)
+        sh = S.soft_shader(kind)
+        w, h = w // 2, h // 2
+        cam = S.default_camera(w, h)
+        seed = 6000 + alias
+        frame = R.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=seed, shading=B.SHADING_SOFT))
+        fn = f"frame_{name}_soft_{kind}_a{alias}.npy"
+        np.save(os.path.join(OUT, fn), frame)
+        meta["soft_cases"].append({"case": name, "lights": kind, "alias": alias, "seed": seed, "width": w, "height": h,
+                                   "file": fn, "fnv1a64": f"{B.fnv1a64(frame):016x}"})
     # 1d. host file formats: small OBJ and BMP files and what the reference's own readers (Mesh::Mesh,
     #     Texture::Texture) make of them
     ldir = os.path.join(OUT, "loaders")
@@ -160,6 +177,17 @@ def main():
     for (w, h, nl) in [(800, 600, 1), (800, 600, 2)]:
         frame = R.render(S.default_scene().pack(), S.default_camera(w, h), S.default_shader(nl), B.opts(w, h))
         meta[f"default_{w}x{h}_{nl}light"] = {"fnv1a64": f"{B.fnv1a64(frame):016x}"}
+    # the default scene at the metric's 3840x2160: a third of the rows by the reference's classes (a thread needs a
+    # minute for the frame), the hash of the whole frame as this build's checker renders it and as a build of the
+    # reference's main.cpp itself was measured to render it
+    w, h = 3840, 2160
+    rows = R.render(S.default_scene().pack(), S.default_camera(w, h), S.default_shader(1), B.opts(w, h, row_begin=720, row_end=1440))
+    from oracle.oracle_py import Oracle
+    O = Oracle()
+    full, _ = O.render(S.default_scene().pack(), S.default_camera(w, h), S.default_shader(1), B.opts(w, h), threads=0)
+    assert np.array_equal(rows[720:1440], full[720:1440])
+    meta["default_3840x2160_1light"] = {"fnv1a64": f"{O.fnv(full):016x}", "rows_720_1440_fnv1a64": f"{O.fnv(rows[720:1440]):016x}"}
+    assert meta["default_3840x2160_1light"]["fnv1a64"] == "b7bc333b9d9ae34d"
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("golden vectors written to", OUT)

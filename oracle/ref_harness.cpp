@@ -220,8 +220,44 @@ View calc_view(const Cam &k, double x_per, double y_per) {
 // (:93-112, thresholds :27-28), refraction branches (:116-154).  The recursion has no bound of its own; `depth`
 // stops a chain that does not end before the stack does and reports it through g_too_deep.
 thread_local int g_too_deep = 0;
+// Soft shadows: Shader::shading (shader.h:42-96) with the call it keeps commented out at :91, CalcSoftShadow, in
+// place of CalcShadow at :90.  That one line cannot be switched from outside the class, so the function's few
+// lines are re-expressed here; everything they call -- TextureMapping, SolidTexture, Get3DFunction, CalcDiffuse,
+// CalcSpecular, CalcBorder and CalcSoftShadow itself -- is the reference's own code.  `light` is the vector the
+// Shader was constructed with (its own copy is private, shader.h:26).
+std::vector<light_src *> *g_soft_lights = nullptr; // non-null: render with soft shadows
+Color shading_soft(Shader &shd, std::vector<light_src *> &light, Color cm0, Color cm1, Point3D ph, Vector3D &nh, View eye,
+                   bool no_border, std::vector<AnyObject *> &objs, int object_index, Vector2D UV, double m, double n) {
+    int light_num = (int)light.size();
+    Color clr_sum = Color(0, 0, 0);
+    Color clr = cm0;
+    if (objs[object_index]->texture_type == 1) {
+        tuple<Color, Color, Vector3D> r = shd.TextureMapping(ph, nh, objs[object_index], false, UV);
+        cm0 = get<0>(r); cm1 = get<1>(r); nh = get<2>(r);
+    } else if (objs[object_index]->texture_type == 2) {
+        tuple<Color, Color> r = shd.SolidTexture(ph, nh, objs[object_index], cm0);
+        cm0 = get<0>(r); cm1 = get<1>(r);
+    } else if (objs[object_index]->texture_type == 3) {
+        cm0 = objs[object_index]->textures[0]->Get3DFunction(ph, Point3D(0, 0, 20));
+        cm1 = shd.ambient_color;
+    }
+    if (objs[object_index]->GetObjectType() == "Environment") return cm0;
+    for (int light_index = 0; light_index < light_num; light_index++) {
+        Vector3D nhl;
+        if (light[light_index]->type == 0) nhl = light[light_index]->direction;
+        else nhl = Normalize(ph - light[light_index]->position);
+        clr = shd.CalcDiffuse(cm0, cm1, ph, nh, eye, nhl, light_index);
+        clr = shd.CalcSpecular(clr, ph, nh, eye, nhl, light_index);
+        if (!no_border) clr = shd.CalcBorder(clr, ph, nh, eye, nhl);
+        clr = shd.CalcSoftShadow(clr, ph, nh, nhl, light_index, objs, m, n);
+        clr_sum = clr_sum / (light_index + 1.0) * light_index + clr / (light_index + 1.0);
+    }
+    return clr_sum;
+}
+// m, n: the last two parameters of CalcSubPixel (main.cpp:42), which it hands to Shader::shading (:88); the calls of
+// the recursion leave them at their default 0 (:109,126,138,148)
 Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd, int reflection_times = 0,
-                double reflection_ktotal = 1.0, int outside = 1, int object_index = 0, int depth = 0) {
+                double reflection_ktotal = 1.0, int outside = 1, int object_index = 0, int depth = 0, double m = 0, double n = 0) {
     double t_min = FLT_MAX;
     Color clr = Color(0, 0, 0);
     Color cm0(0, 0, 0);
@@ -251,7 +287,8 @@ Color sub_pixel(View eye, std::vector<AnyObject *> &objs, Shader &shd, int refle
         }
     }
     if (t_min != FLT_MAX)
-        clr = shd.shading(cm0, shd.ambient_color, ph, nh, eye, no_border, objs, object_index, UV, 0, 0);
+        clr = g_soft_lights ? shading_soft(shd, *g_soft_lights, cm0, shd.ambient_color, ph, nh, eye, no_border, objs, object_index, UV, m, n)
+                            : shd.shading(cm0, shd.ambient_color, ph, nh, eye, no_border, objs, object_index, UV, m, n);
     double ks = objs[object_index]->ks;
     reflection_ktotal *= ks;
     if (outside >= 1) reflection_times++;
@@ -325,6 +362,7 @@ std::vector<light_src *> make_lights(const rt355_shader *sh) {
         const rt355_light &l = sh->lights[i];
         light_src *p = new light_src(l.type, pnt(l.position), vec(l.direction), vec(l.color));
         p->direction = vec(l.direction); // the descriptor holds the member as stored
+        p->n0 = vec(l.n0); p->n1 = vec(l.n1); p->sx = l.sx; p->sy = l.sy; // the area (light.h:19-23,49-53)
         ls.push_back(p);
     }
     return ls;
@@ -347,8 +385,15 @@ int ref_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const 
     std::vector<Vector3D> geo;
     for (int i = 0; i < n_dirs; i++) geo.push_back(Vector3D(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
     const int shading = opts->shading;
+    const int alias_ = opts->alias;
     auto shade = [&](View eye, std::vector<AnyObject *> &objs, Shader &shd, int x, int y, int sample) {
         if (shading == RT355_SHADING_LIGHTS) return sub_pixel(eye, objs, shd);
+        if (shading == RT355_SHADING_SOFT) { // the call of main.cpp:312 / :330, see rt355x_soft_args
+            int32_t object_index = 0; double m = 0, n = 0;
+            if (alias_ > 0) rt355x_soft_args(opts->seed, x, y, sample % alias_, sample / alias_, alias_, &object_index, &m, &n);
+            if (object_index >= (int)objs.size()) object_index = 0;
+            return sub_pixel(eye, objs, shd, 0, 1.0, 1, object_index, 0, m, n);
+        }
         g_draw.seed = opts->seed; g_draw.x = x; g_draw.y = y; g_draw.sample = sample; g_draw.drawn = 0;
         return sub_pixel2(eye, objs, shd, geo, shading);
     };
@@ -358,6 +403,7 @@ int ref_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const 
     Shader shd(ls, Color(sh->ambient[0], sh->ambient[1], sh->ambient[2]),
                Color(sh->specular[0], sh->specular[1], sh->specular[2]),
                Color(sh->border[0], sh->border[1], sh->border[2]));
+    g_soft_lights = (shading == RT355_SHADING_SOFT) ? &ls : nullptr;
     Cam k = set_camera(cam);
     int W = opts->width, H = opts->height;
     int y0 = opts->row_begin, y1 = opts->row_end;
@@ -385,6 +431,7 @@ int ref_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, const 
             size_t i = ((size_t)y * W + x) * 3;
             pixmap[i] = c.r; pixmap[i + 1] = c.g; pixmap[i + 2] = c.b;
         }
+    g_soft_lights = nullptr;
     for (light_src *l : ls) delete l;
     if (g_too_deep) { g_too_deep = 0; return -2; } // a refraction chain that did not end
     return 0;

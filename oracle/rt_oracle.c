@@ -446,10 +446,11 @@ typedef struct {
     const rt355_shader *sh;
     uint64_t shadow_rays;
     uint64_t secondary_rays;
-    const double *dirs; /* geo, main.cpp:557 */
+    const double *dirs; /* geo, main.cpp:639 */
     int n_dirs;
     uint64_t gather_rays;
     int too_deep; /* a refraction chain that does not end (see calc_subpixel_rec) */
+    int soft;     /* Shader::shading calls CalcSoftShadow (shader.h:91) in place of CalcShadow (:90) */
 } octx;
 
 static col calc_diffuse(const rt355_light *L, col cm0, col cm1, v3 nh, v3 nhl) { /* shader.h:324-338 */
@@ -496,9 +497,37 @@ static col calc_shadow(octx *cx, const rt355_light *L, col clr, v3 ph, v3 nh, v3
     return cadd(cmul(clr, shd), cmul(C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), 1 - shd));
 }
 
-/* Shader::shading, shader.h:42-96 */
+/* CalcSoftShadow, shader.h:439-483: the shadow ray aims at a point of lights[0]'s area (whichever light i is
+ * being shaded, :441-443), nlh is not normalised before the facing test (:445-446; the View constructor
+ * normalises the ray's direction), L is the distance to light i's position (:462). */
+static col calc_soft_shadow(octx *cx, const rt355_light *L, col clr, v3 ph, v3 nh, v3 nhl, double m, double n) {
+    const rt355_shader *sh = cx->sh;
+    const rt355_light *L0 = &sh->lights[0];
+    double shd = 1;
+    v3 pl = from3(L0->position);
+    pl = vadd(vadd(pl, vmul(vmul(from3(L0->n0), L0->sx), m)), vmul(vmul(from3(L0->n1), L0->sy), n)); /* :443 */
+    v3 nlh = vsub(pl, ph);                                                                          /* :445 */
+    if (dot(nh, nlh) <= 0) {
+        shd = 0.5;
+    } else {
+        int no = cx->s->d->n_objects;
+        double t_min = FLT_MAX;
+        ray sr = mkview(ph, nlh);
+        cx->shadow_rays++;
+        for (int i = 0; i < no; i++) {
+            hit h = obj_isect(cx->s, i, sr);
+            if (h.t >= 0 && h.t < t_min) t_min = h.t;
+        }
+        double Ld = vlen(vsub(from3(L->position), ph));
+        if (t_min > 0 && t_min < Ld) shd = t_min / Ld;
+    }
+    if (L->type == 2) shd = shd * ((dot(from3(L->direction), nhl) + 1) / 2.0);
+    return cadd(cmul(clr, shd), cmul(C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), 1 - shd));
+}
+
+/* Shader::shading, shader.h:42-96; m, n: its last two parameters, which only CalcSoftShadow reads */
 static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_border, int obj,
-                   double uvx, double uvy) {
+                   double uvx, double uvy, double m, double n) {
     const rt355_object *o = &cx->s->d->objects[obj];
     const rt355_shader *sh = cx->sh;
     col clr_sum = C(0, 0, 0);
@@ -514,7 +543,8 @@ static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_bor
         col clr = calc_diffuse(L, cm0, cm1, nh, nhl);
         clr = calc_specular(sh, L, clr, nh, eye, nhl);
         if (!no_border) clr = calc_border(sh, clr, ph, nh, eye);
-        clr = calc_shadow(cx, L, clr, ph, nh, nhl);
+        if (cx->soft) clr = calc_soft_shadow(cx, L, clr, ph, nh, nhl, m, n);   /* shader.h:91 */
+        else clr = calc_shadow(cx, L, clr, ph, nh, nhl);                       /* shader.h:90 */
         clr_sum = cadd(cmul(cdivd(clr_sum, k + 1.0), k), cdivd(clr, k + 1.0));
     }
     return clr_sum;
@@ -531,7 +561,7 @@ static col shading(octx *cx, col cm0, col cm1, v3 ph, v3 nh, ray eye, int no_bor
  * reference's stack; here it sets too_deep. */
 #define ORACLE_MAX_DEPTH 2000
 static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double reflection_ktotal, int outside,
-                             int object_index, int depth) {
+                             int object_index, int depth, double soft_m, double soft_n) {
     int n = cx->s->d->n_objects;
     double t_min = FLT_MAX;
     hit best; memset(&best, 0, sizeof best);
@@ -554,7 +584,7 @@ static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double ref
             const rt355_shader *sh = cx->sh;
             clr = shading(cx, C(o->rgb[0], o->rgb[1], o->rgb[2]),
                           C(sh->ambient[0], sh->ambient[1], sh->ambient[2]), best.ph, best.nh, eye,
-                          no_border, idx, best.uvx, best.uvy);
+                          no_border, idx, best.uvx, best.uvy, soft_m, soft_n);
         }
     }
     if (n == 0) return clr; /* the reference would read objs[0] of an empty vector here */
@@ -567,7 +597,7 @@ static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double ref
         v3 reflect_npe = vsub(eye.npe, vmul(vmul(best.nh, 2), dot(best.nh, eye.npe))); /* :104 */
         ray reflect_view = mkview(best.ph, reflect_npe);                      /* :108 */
         cx->secondary_rays++;
-        col sub = calc_subpixel_rec(cx, reflect_view, reflection_times, reflection_ktotal, 1, 0, depth + 1);
+        col sub = calc_subpixel_rec(cx, reflect_view, reflection_times, reflection_ktotal, 1, 0, depth + 1, 0, 0);
         clr_reflection = cadd(cmul(clr, 1 - ks), cmul(sub, ks));               /* :109 */
     }
     double fresnel = o->fresnel;                                               /* :116 */
@@ -579,7 +609,7 @@ static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double ref
         v3 T = vadd(vmul(Vv, -IOR), vmul(best.nh, IOR * c - sqrt((IOR * c) * (IOR * c) - IOR * IOR + 1))); /* :123 */
         T = normalize(T);                                                      /* :124 */
         cx->secondary_rays++;
-        col clr_refraction = calc_subpixel_rec(cx, mkview(best.ph, T), reflection_times, reflection_ktotal, -1, idx, depth + 1);
+        col clr_refraction = calc_subpixel_rec(cx, mkview(best.ph, T), reflection_times, reflection_ktotal, -1, idx, depth + 1, 0, 0);
         return cadd(cmul(clr_reflection, fresnel), cmul(clr_refraction, 1 - fresnel)); /* :127 */
     }
     double IOR = o->ior;                                                       /* :131 */
@@ -587,13 +617,20 @@ static col calc_subpixel_rec(octx *cx, ray eye, int reflection_times, double ref
     cx->secondary_rays++;
     if (delta > 0) {
         v3 T = normalize(vadd(vmul(Vv, -IOR), vmul(best.nh, IOR * c - sqrt(delta)))); /* :135-136 */
-        return calc_subpixel_rec(cx, mkview(best.ph, T), reflection_times, reflection_ktotal, 1, idx, depth + 1); /* :138,150 */
+        return calc_subpixel_rec(cx, mkview(best.ph, T), reflection_times, reflection_ktotal, 1, idx, depth + 1, 0, 0); /* :138,150 */
     }
     v3 reflect_npe = vsub(eye.npe, vmul(vmul(best.nh, 2), dot(best.nh, eye.npe))); /* :142 */
     if (outside-- <= -5) outside = 1;                                          /* :144-146 */
-    return calc_subpixel_rec(cx, mkview(best.ph, reflect_npe), reflection_times, reflection_ktotal, outside, idx, depth + 1); /* :148,150 */
+    return calc_subpixel_rec(cx, mkview(best.ph, reflect_npe), reflection_times, reflection_ktotal, outside, idx, depth + 1, 0, 0); /* :148,150 */
 }
-static col calc_subpixel(octx *cx, ray eye) { return calc_subpixel_rec(cx, eye, 0, 1.0, 1, 0, 0); }
+static col calc_subpixel(octx *cx, ray eye) { return calc_subpixel_rec(cx, eye, 0, 1.0, 1, 0, 0, 0, 0); }
+/* the call of main.cpp:312 for sub-sample (p, q) of pixel (x, y): see rt355x_soft_args */
+static col calc_subpixel_soft(octx *cx, ray eye, uint32_t seed, int x, int y, int p, int q, int alias) {
+    int32_t object_index; double m, n;
+    rt355x_soft_args(seed, x, y, p, q, alias, &object_index, &m, &n);
+    if (object_index >= cx->s->d->n_objects) object_index = 0; /* (the reference would index past its vector) */
+    return calc_subpixel_rec(cx, eye, 0, 1.0, 1, object_index, 0, m, n);
+}
 
 /* sin and cos of the gather rotation, correctly rounded (evaluated in binary128 by libquadmath, rounded
  * once).  The reference calls its C library's sin and cos; those differ between libraries in the last bit
@@ -736,7 +773,8 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
     if (y0 == 0 && y1 == 0) y1 = H;
     if (stride < 1) stride = 1;
     uint64_t prim = 0, shad = 0, sec = 0, gat = 0, deep = 0;
-    const int shading = opts->shading;
+    const int soft = opts->shading == RT355_SHADING_SOFT;
+    const int shading = soft ? 0 : opts->shading; /* != 0: CalcSubPixel2 with a gather shader */
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
@@ -749,7 +787,7 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
         /* interleaved row tiles (rt355_opts.tile_*): only the rows of this call's share */
         if (opts->tile_count > 1 && opts->tile_rows > 0 && ((y - y0) / opts->tile_rows) % opts->tile_count != opts->tile_phase) continue;
         octx cx; cx.s = &s; cx.sh = sh; cx.shadow_rays = 0; cx.secondary_rays = 0;
-        cx.dirs = dirs; cx.n_dirs = n_dirs; cx.gather_rays = 0; cx.too_deep = 0;
+        cx.dirs = dirs; cx.n_dirs = n_dirs; cx.gather_rays = 0; cx.too_deep = 0; cx.soft = soft;
         const int alias = opts->alias;
         for (int x = 0; x < W; x += stride) {
             col clr;
@@ -761,7 +799,7 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
                         double pointY = (rt355x_jitter(opts->seed, x, y, q * alias + p, 1) + q) / alias + y; /* :293 */
                         ray eye = calc_view(&c, pointX / W, pointY / H);
                         col sub = shading ? calc_subpixel2(&cx, eye, shading, opts->seed, x, y, q * alias + p)
-                                          : calc_subpixel(&cx, eye);
+                                          : (soft ? calc_subpixel_soft(&cx, eye, opts->seed, x, y, p, q, alias) : calc_subpixel(&cx, eye));
                         red += sub.r; green += sub.g; blue += sub.b;                                         /* :315-317 */
                         prim++;
                     }
@@ -794,6 +832,7 @@ int rt_oracle_render_gather(const rt355_scene_desc *d, const rt355_camera *cam, 
 
 /* Known-answer probes (one call = one reference function). */
 
+double rt_oracle_strata(uint32_t seed, int32_t x, int32_t y, int32_t which) { return rt355x_strata(seed, x, y, which); }
 double rt_oracle_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim) {
     return rt355x_jitter(seed, x, y, sample, dim);
 }

@@ -99,7 +99,7 @@ class Renderer:
         return out, st.as_dict()
 
     def set_directions(self, dirs):
-        """The direction set `geo` of the gather shaders (main.cpp:557), (n, 3) float64 as Geodesic() leaves it."""
+        """The direction set `geo` of the gather shaders (main.cpp:639), (n, 3) float64 as Geodesic() leaves it."""
         d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
         _check(lib().rt355_scene_set_directions(self.handle, d.ctypes.data if len(d) else None, len(d)),
                "rt355_scene_set_directions")

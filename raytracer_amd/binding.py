@@ -20,7 +20,7 @@ QUADRIC_KINDS = {"Quadric": (0, 0, 0, 1, 0), "Cone": (1, 1, -1, 0, 0), "Ellipsoi
                  "Cylinder": (1, 1, 0, 0, -1), "EllipticParaboloid": (1, 1, 0, -1, 0),
                  "HyperbolicParaboloid": (1, -1, 0, -1, 0)}
 MODE_ALLPAIRS, MODE_BRUTE, MODE_PACKET = 0, 1, 2
-SHADING_LIGHTS, SHADING_OCCLUSION, SHADING_BLEED = 0, 1, 2
+SHADING_LIGHTS, SHADING_OCCLUSION, SHADING_BLEED, SHADING_SOFT = 0, 1, 2, 3
 
 ERR = {0: "OK", -1: "ERR_ARG", -2: "ERR_UNSUPPORTED", -3: "ERR_DEVICE", -4: "ERR_NOMEM"}
 
@@ -35,13 +35,13 @@ OBJECT_DTYPE = np.dtype(
         "itemsize": 232,
     }
 )
-# struct rt355_light (80 bytes)
+# struct rt355_light (144 bytes)
 LIGHT_DTYPE = np.dtype(
     {
-        "names": ["position", "direction", "color", "type", "pad_"],
-        "formats": [("f8", 3), ("f8", 3), ("f8", 3), "i4", "i4"],
-        "offsets": [0, 24, 48, 72, 76],
-        "itemsize": 80,
+        "names": ["position", "direction", "color", "type", "pad_", "n0", "n1", "sx", "sy"],
+        "formats": [("f8", 3), ("f8", 3), ("f8", 3), "i4", "i4", ("f8", 3), ("f8", 3), "f8", "f8"],
+        "offsets": [0, 24, 48, 72, 76, 80, 104, 128, 136],
+        "itemsize": 144,
     }
 )
 
@@ -245,14 +245,17 @@ class PackedScene:
         self.desc = d
 
 
-def light_src(type_: int, position, direction, color=(1, 1, 1)) -> np.void:
+def light_src(type_: int, position, direction, color=(1, 1, 1), n0=(1, 0, 0), n1=(0, 1, 0), sx=1.0, sy=1.0) -> np.void:
     """light_src(int type, Point3D position, Vector3D direction, Vector3D color), light.h:27-32:
-    the stored direction is Normalize(direction_in)."""
+    the stored direction is Normalize(direction_in).  n0, n1, sx, sy: the area of the type 3 constructor
+    (light.h:44-54, stored as given; n2 is read nowhere); the other constructors leave the defaults of
+    light.h:19-23, which CalcSoftShadow reads all the same when the light is lights[0]."""
     l = np.zeros((), dtype=LIGHT_DTYPE)
     l["type"] = type_
     l["position"] = position
     l["direction"] = _normalize(direction)
     l["color"] = color
+    l["n0"] = n0; l["n1"] = n1; l["sx"] = sx; l["sy"] = sy
     return l
 
 
@@ -308,6 +311,15 @@ def _keyed(seed, x, y, sample, dim):
 def jitter(seed, x, y, sample, dim) -> float:
     """rt355_jitter of include/rt355.h (the jitter of CalcPixel, main.cpp:292-293, from a counter-based generator)."""
     return (_keyed(seed, x, y, sample, dim) >> 33) / 2147483647.0
+
+
+def strata(seed, x, y, which) -> float:
+    """rt355_strata of include/rt355.h (k0, k1 and r of CalcPixel, main.cpp:286-288)."""
+    z = _mix64(seed & 0xFFFFFFFF)
+    z = _mix64(z ^ (x & 0xFFFFFFFF))
+    z = _mix64(z ^ (y & 0xFFFFFFFF))
+    z = _mix64(z ^ (which & 0xFFFFFFFF))
+    return (_mix64(z ^ 0x737472617461) >> 33) / 2147483647.0
 
 
 def rotation(seed, x, y, sample, axis) -> float:

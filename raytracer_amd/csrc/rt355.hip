@@ -137,6 +137,7 @@ struct Frame {
     // (the rays of a wave are a 16 x 16 block of every other pixel: their own byte stores leave every line of the
     // pixmap half written by workgroups that run on other XCDs).
     int32_t deferred;
+    int32_t soft; // RT355_SHADING_SOFT: Shader::shading calls CalcSoftShadow (shader.h:91) in place of CalcShadow (:90)
 };
 // row of the frame that local row `y` of the call is (local rows are the rows rendered, in order)
 __device__ __forceinline__ int frame_row(const Frame &f, int y) {
@@ -1677,7 +1678,8 @@ __global__ __launch_bounds__(256) void k_average(Frame f, const uint32_t *__rest
 // each ray goes to the light's slot, and rays of binned bundles are counted into direction bins.
 // Called by all lanes of a wave; returns the number of shadow rays this lane's hit needs.
 __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const Group &gr, const Work &w,
-                                                     uint32_t rid, bool in_range, bool hit, d3 ph, d3 nh) {
+                                                     uint32_t rid, bool in_range, bool hit, d3 ph, d3 nh, bool soft) {
+    if (soft) return 0u; // (the shadow rays of CalcSoftShadow share neither origin nor direction: none is searched, and the shading kernel counts them)
     uint32_t n_shadow = 0;
     // the counter value every lane's cell had before this wave arrived, still in flight (one returning
     // atomic per light): all lights' atomics are issued before any result is used
@@ -1791,16 +1793,42 @@ __device__ __forceinline__ HitRec primary_record(const SceneView &s, const Shade
 }
 // One turn of Shader::shading's light loop (shader.h:74-93): colour before the shadow, CalcShadow with the
 // closest occluder's distance from `occluder(shadow ray)`, running mean.
-template <class Occluder>
+// What CalcSubPixel receives from CalcPixel for grid point (gx, gy) under RT355_SHADING_SOFT (rt355x_soft_args in
+// rt355.h): the object a ray that misses goes on with, and Shader::shading's m and n.
+struct SoftArgs { int obj0; double m, n; };
+__device__ __forceinline__ SoftArgs soft_args(const Frame &f, int gx, int gy) {
+    SoftArgs a; a.obj0 = 0; a.m = 0; a.n = 0;
+    if (f.soft && f.alias > 0) {
+        int32_t o;
+        rt355x_soft_args(f.seed, gx / f.alias, frame_row(f, gy / f.alias), gx % f.alias, gy % f.alias, f.alias, &o, &a.m, &a.n);
+        a.obj0 = o;
+    }
+    return a;
+}
+// SOFT: CalcSoftShadow (shader.h:439-483) in place of CalcShadow -- the shadow ray aims at the point
+// lights[0].position + n0 * sx * m + n1 * sy * n of lights[0]'s area whichever light is being shaded (:441-443), the
+// facing test takes the vector to that point as it is (:445-446), L stays the distance to light k's position (:462).
+template <bool SOFT = false, class Occluder>
 __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, const HitRec &h, uint32_t sum,
-                                                Occluder occluder, uint32_t &n_shadow) {
+                                                Occluder occluder, uint32_t &n_shadow, double soft_m = 0, double soft_n = 0) {
     const DLight &L = sh.lights[k];
     const d3 nhl = light_nhl(L, h.ph);
     uint32_t clr = calc_diffuse(L, h.cm0, h.cm1, h.nh, nhl);
     clr = calc_specular(sh, L, clr, h.reh, nhl);
     if (!h.no_border) clr = calc_border(sh, clr, h.border_w);
     double shd = 0.5; // shader.h:396-398
-    if (!(dot(h.nh, vmul(nhl, -1)) <= 0)) {
+    if (SOFT) {
+        const DLight &L0 = sh.lights[0];
+        d3 pl = ld3(L0.position);
+        pl = vadd(vadd(pl, vmul(vmul(ld3(L0.n0), L0.sx), soft_m)), vmul(vmul(ld3(L0.n1), L0.sy), soft_n)); // :443
+        const d3 nlh = vsub(pl, h.ph);                                                                      // :445
+        if (!(dot(h.nh, nlh) <= 0)) {
+            const double t_min = occluder(mkview(h.ph, nlh));                                               // :454
+            const double Ld = vlen(vsub(ld3(L.position), h.ph));                                            // :462
+            shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
+            n_shadow += 1;
+        }
+    } else if (!(dot(h.nh, vmul(nhl, -1)) <= 0)) {
         Ray sr; // View(ph, nhl * (-1)), shader.h:395,404
         if (L.type == 0) { sr.pe = h.ph; sr.npe = ld3(L.shadow_dir); }
         else sr = mkview(h.ph, vmul(nhl, -1));
@@ -1822,7 +1850,7 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
 // this.  Compiled apart so that scenes without mirrors do not carry the loop, and (ENV) scenes without an
 // Environment not its tests.
 // (REFLECT: three waves per SIMD -- left alone the compiler takes 207 registers, two waves, and 26 % longer)
-template <bool REFLECT, bool ENV>
+template <bool REFLECT, bool ENV, bool SOFT = false>
 __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                        unsigned char *__restrict__ pixmap) {
     const uint32_t rid = 0; // (no per-ray lists on this path)
@@ -1836,6 +1864,7 @@ __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneVie
     Ray e = grid_ray(cam, f, x, y);
     Spill none; none.pool = nullptr; none.count = nullptr;
     constexpr int LEVELS = REFLECT ? 4 : 1;
+    const SoftArgs soft = SOFT ? soft_args(f, x, y) : SoftArgs{0, 0.0, 0.0};
     uint32_t level_clr[LEVELS];
     double level_ks[LEVELS];
     int deepest = 0;
@@ -1850,18 +1879,18 @@ __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneVie
         closest_hit<false, ENV>(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
         uint32_t sum = 0u; // main.cpp:83: no hit -> Color(0,0,0); no lights -> clr_sum = (0,0,0), shader.h:49,95
         d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
-        int obj = 0;
+        int obj = (SOFT && level == 0 && soft.obj0 < s.n_objects) ? soft.obj0 : 0; // what a ray that misses goes on with (main.cpp:94)
         if (c.prim_best >= 0) {
             if (level == 0) n_hit = 1;
             const HitRec h = primary_record<ENV>(s, sh, e, c);
             ph = h.ph; nh = h.nh; obj = h.obj;
             if (h.emissive) sum = h.cm0;
             for (int k = 0; !h.emissive && k < sh.n_lights; k++)
-                sum = shade_light(sh, k, h, sum, [&](const Ray &sr) {
+                sum = shade_light<SOFT>(sh, k, h, sum, [&](const Ray &sr) {
                     Closest o;
                     closest_hit<false, ENV>(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
                     return o.t_best;
-                }, n_shadow);
+                }, n_shadow, level == 0 ? soft.m : 0.0, level == 0 ? soft.n : 0.0);
         }
         level_clr[level] = sum;
         if (REFLECT) {
@@ -1968,6 +1997,7 @@ __device__ __forceinline__ void intersect_inside(const SceneView &s, int obj, co
     *ph_out = ph; *nh_out = nh;
 }
 // (three waves per SIMD: at the two the compiler picks by itself the frame takes 30 % longer, at four the spills cost more)
+template <bool SOFT>
 __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                         unsigned char *__restrict__ pixmap) {
     const uint32_t rid = 0; // (no per-ray lists on this path)
@@ -1983,7 +2013,8 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
     uint32_t op_clr[REFRACT_OPS], op_what[REFRACT_OPS]; // what = object | kind << 30
     RefractSpawn spawn[REFRACT_SPAWNS];
     int n_ops = 0, n_spawn = 0;
-    int times = 0, outside = 1, oi = 0;
+    const SoftArgs soft = SOFT ? soft_args(f, x, y) : SoftArgs{0, 0.0, 0.0};
+    int times = 0, outside = 1, oi = (SOFT && soft.obj0 < s.n_objects) ? soft.obj0 : 0;
     double ktotal = 1.0;
     uint32_t value = 0u;
     bool first = true;
@@ -2003,11 +2034,11 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
                 ph = h.ph; nh = h.nh; oi = h.obj;
                 if (h.emissive) own = h.cm0;
                 for (int k = 0; !h.emissive && k < sh.n_lights; k++)
-                    own = shade_light(sh, k, h, own, [&](const Ray &sr) {
+                    own = shade_light<SOFT>(sh, k, h, own, [&](const Ray &sr) {
                         Closest o;
                         closest_hit(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
                         return o.t_best;
-                    }, n_shadow);
+                    }, n_shadow, first ? soft.m : 0.0, first ? soft.n : 0.0);
             }
         }
         first = false;
@@ -2431,7 +2462,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u) | (h.emissive ? (1u << 25) : 0u) | (far ? (1u << 26) : 0u);
     w.rec_cm1[rid] = h.cm1;
     } while (0);
-    const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, got_hit && sh.n_lights, ph, nh);
+    const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, got_hit && sh.n_lights, ph, nh, f.soft != 0);
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
@@ -2461,7 +2492,9 @@ __global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, 
         e.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
     }
     const int obj = w.rec_obj[rid];
-    const double ks = s.n_objects > 0 ? s.objects[obj >= 0 ? obj : 0].ks : 0.0; // main.cpp:94
+    int miss_obj = 0; // what a ray that misses goes on with: object_index as CalcSubPixel received it
+    if (f.soft && level == 0) { const SoftArgs a = soft_args(f, x, y); if (a.obj0 < s.n_objects) miss_obj = a.obj0; }
+    const double ks = s.n_objects > 0 ? s.objects[obj >= 0 ? obj : miss_obj].ks : 0.0; // main.cpp:94
     w.lvl_ks[(size_t)level * n + rid] = ks;
     const double ktotal = w.ktotal[rid] * ks;                                    // :97
     w.ktotal[rid] = ktotal;
@@ -2544,11 +2577,13 @@ __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, F
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4 // waves per SIMD the shading kernel's register budget allows
 #endif
-template <bool ENV> // the scene holds an Environment or a quadric (their tests are compiled out otherwise)
+// ENV: the scene holds an Environment or a quadric (their tests are compiled out otherwise).  SOFT: CalcSoftShadow
+// (every shadow ray goes through the fp64 walk over everything: `cur` holds no searched bundle).
+template <bool ENV, bool SOFT = false>
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView s, ShaderView sh, Frame f, Work w, Group cur,
                                                      Group next, unsigned char *__restrict__ pixmap) {
     uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_eval = 0, n_over = 0;
+    uint32_t n_eval = 0, n_over = 0, n_soft = 0;
 #ifdef RT355_DEBUG_SURVIVORS
     uint32_t dbg_n[LIGHT_GROUP] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -2580,15 +2615,17 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     }
     h.border_w = h.no_border ? 0.0 : w.rec_d[9 * n + rid];
     uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
+    // (the rays of the levels after the camera rays' are cast by the recursion, which passes neither m nor n)
+    const SoftArgs soft = (SOFT && f.level <= 0) ? soft_args(f, x, y) : SoftArgs{0, 0.0, 0.0};
     for (int g = 0; g < cur.count; g++) {
-        sum = shade_light(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
+        sum = shade_light<SOFT>(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
             Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_STRIDE(n); sp.count = w.spill.count + g;
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
-            return nearest_occluder<ENV>(s, sr, cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+            return nearest_occluder<ENV>(s, sr, SOFT || cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
                                     w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
-        }, unused);
+        }, SOFT ? n_soft : unused, soft.m, soft.n);
     }
     if (last) {
         store_pixel(pixmap, f, w, rid, x, y, sum);
@@ -2598,9 +2635,10 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     hit = true;
     } while (0);
     if (!last) {
-        const uint32_t n_shadow = emit_shadow_rays(sh, next, w, rid, rid < f.n_rays, hit, ph, nh);
+        const uint32_t n_shadow = emit_shadow_rays(sh, next, w, rid, rid < f.n_rays, hit, ph, nh, SOFT);
         wave_count(w.counters, 0, n_shadow);
     }
+    if (SOFT) wave_count(w.counters, 0, n_soft);
 #ifdef RT355_DEBUG_SURVIVORS
     for (int g = 0; g < LIGHT_GROUP; g++) { // lane slots the candidate loops occupy vs candidates tested
         uint32_t mx = dbg_n[g];
@@ -2755,6 +2793,9 @@ extern "C" double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t samp
 }
 extern "C" double rt355_rotation(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t axis) {
     return rt355x_rotation(seed, x, y, sample, axis);
+}
+extern "C" double rt355_strata(uint32_t seed, int32_t x, int32_t y, int32_t which) {
+    return rt355x_strata(seed, x, y, which);
 }
 extern "C" int rt355_sincos(double x, double *sin_out, double *cos_out) {
     if (!sin_out || !cos_out || !(x >= 0 && x < 8)) return fail(RT355_ERR_ARG, "rt355_sincos: 0 <= x < 8");
@@ -3316,8 +3357,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     const int y0 = rows.y0;
     if (opts->mode != RT355_MODE_ALLPAIRS && opts->mode != RT355_MODE_BRUTE && opts->mode != RT355_MODE_PACKET)
         return fail(RT355_ERR_ARG, "unknown mode");
-    if (opts->shading != RT355_SHADING_LIGHTS && opts->shading != RT355_SHADING_OCCLUSION && opts->shading != RT355_SHADING_BLEED)
+    if (opts->shading != RT355_SHADING_LIGHTS && opts->shading != RT355_SHADING_OCCLUSION && opts->shading != RT355_SHADING_BLEED &&
+        opts->shading != RT355_SHADING_SOFT)
         return fail(RT355_ERR_ARG, "unknown shading");
+    const bool soft = opts->shading == RT355_SHADING_SOFT;
+    const bool lit = soft || opts->shading == RT355_SHADING_LIGHTS; // CalcSubPixel with Shader::shading (not CalcSubPixel2)
     HIP_TRY(hipSetDevice(sc->device));
     if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     hipStream_t st = (hipStream_t)hip_stream;
@@ -3349,15 +3393,16 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     // of the scene bounds the number of levels.
     // refraction (Shader::shading's renderer only: CalcSubPixel2 does not recurse) is rendered unsearched, one
     // thread per pixel walking its whole tree of rays
-    const bool refract = sc->refractive && opts->shading == RT355_SHADING_LIGHTS;
+    const bool refract = sc->refractive && lit;
     const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
     int extra_levels = 0;
-    if (can_search && sc->reflective && opts->shading == RT355_SHADING_LIGHTS) {
+    if (can_search && sc->reflective && lit) {
         double k = 1.0;
         while (extra_levels < 3 && (k *= sc->ks_abs_max) >= 0.05) extra_levels++;
     }
     const bool levels = extra_levels > 0;
-    const bool gather_searched = can_search && opts->shading != RT355_SHADING_LIGHTS;
+    const bool gather_searched = can_search && !lit;
+    f.soft = soft ? 1 : 0;
     f.deferred = can_search ? 1 : 0;
     int rc = RT355_OK;
     unsigned char *na = nullptr; // the no-alloc array of this device
@@ -3393,6 +3438,8 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         memcpy(hl[i].color, l.color, sizeof hl[i].color);
         hl[i].type = l.type; hl[i].pad_ = 0;
         put3(hl[i].shadow_dir, hnormalize(hmul(H3(l.direction), -1.0)));
+        memcpy(hl[i].n0, l.n0, sizeof hl[i].n0); memcpy(hl[i].n1, l.n1, sizeof hl[i].n1);
+        hl[i].sx = l.sx; hl[i].sy = l.sy;
     }
     DLight *d_lights = nullptr;
     if (noalloc) {
@@ -3419,7 +3466,6 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
 
     // bundle 0 = camera rays (common origin: the eye); bundle 1+k = shadow rays of light k (common
     // origin: the light position, or common direction for a directional light)
-    const bool gather = opts->shading != RT355_SHADING_LIGHTS;
     if (gather_searched && !sc->has_general) return fail(RT355_ERR_ARG, "internal: the scene table for gather rays is missing");
     if (levels && !sc->has_general) return fail(RT355_ERR_ARG, "internal: the scene table for mirror rays is missing");
     std::vector<Bundle> bundles(can_search ? 2 + nl : 0); // (unsearched frames have none: no allocation on that path)
@@ -3428,7 +3474,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         bundles[0].kind = 1;
         bundles[0].eye = 1;
         bundles[0].o.x = dc.p_eye[0]; bundles[0].o.y = dc.p_eye[1]; bundles[0].o.z = dc.p_eye[2];
-        for (int k = 0; k < nl; k++) {
+        for (int k = 0; k < nl && !soft; k++) { // (soft shadows: no bundle, every shadow ray takes the fp64 walk)
             Bundle &b = bundles[1 + k];
             if (hl[k].type != 0) {
                 b.kind = 1;
@@ -3597,7 +3643,10 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
 #undef LAUNCH_GATHER
 #define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
         else if (refract) {
-            hipLaunchKernelGGL(k_render_refract, dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+            if (soft) hipLaunchKernelGGL(k_render_refract<true>, dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+            else hipLaunchKernelGGL(k_render_refract<false>, dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+        } else if (soft) {
+            hipLaunchKernelGGL((k_render_direct<true, true, true>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
         } else if (sc->reflective) {
             if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(true, true); else LAUNCH_DIRECT(true, false);
         } else {
@@ -3662,7 +3711,9 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             if ((rc1 = clear_bins(next))) return rc1;
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
             hipLaunchKernelGGL(k_shade_far, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur);
-            if (sc->view.n_envs + sc->view.n_quadrics > 0)
+            if (soft)
+                hipLaunchKernelGGL((k_shade_group<true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
+            else if (sc->view.n_envs + sc->view.n_quadrics > 0)
                 hipLaunchKernelGGL(k_shade_group<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
             else
                 hipLaunchKernelGGL(k_shade_group<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
@@ -3926,7 +3977,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // a call that renders a share of interleaved row tiles is one part
     // a searched frame is a chain of a dozen launches whose cost does not shrink with the rows: one part
     int n_parts = 1;
-    const bool refract = sc->refractive && opts->shading == RT355_SHADING_LIGHTS;
+    const bool refract = sc->refractive && (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
     const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
     if (opts->tile_count <= 1 && !searched) {
         n_parts = 6;

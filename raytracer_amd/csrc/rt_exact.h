@@ -102,6 +102,7 @@ struct DLight {
     // directional light: the shadow rays' direction Normalize(-direction) (shader.h:395, view.h:23), the same for
     // every hit, evaluated once on the host (IEEE sqrt and division, the operations the device would repeat)
     double shadow_dir[3];
+    double n0[3], n1[3], sx, sy; // the light's area (light.h:19-23), read by CalcSoftShadow of lights[0] (shader.h:441-443)
 };
 struct DCamera { // Scene::SetCamera's results (main.cpp:255-262), computed on the host in double
     double p_eye[3], p00[3], n0[3], n1[3];

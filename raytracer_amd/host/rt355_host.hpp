@@ -202,8 +202,17 @@ public:
 
 struct light_src { // light.h:12-56
     int type; Point3D position; Vector3D direction; Vector3D color;
+    Vector3D n0{1, 0, 0}, n1{0, 1, 0}, n2{0, 0, 1}; // the area of a type 3 light (light.h:19-23)
+    double sx = 1, sy = 1;
+    double spot_angle = 20;                        // (read by the hard spot light only, which is compiled out: shader.h:21)
     light_src(int type_in, Point3D position_in, Vector3D direction_in, Vector3D color_in)
         : type(type_in), position(position_in), direction(Normalize(direction_in)), color(color_in) {}
+    light_src(int type_in, Point3D position_in, Vector3D direction_in, Vector3D color_in, double spot_angle_in)
+        : type(type_in), position(position_in), direction(Normalize(direction_in)), color(color_in), spot_angle(spot_angle_in) {}
+    light_src(int type_in, Point3D position_in, Vector3D direction_in, Vector3D color_in, Vector3D n0_in, Vector3D n1_in,
+              Vector3D n2_in, double sx_in, double sy_in)
+        : type(type_in), position(position_in), direction(Normalize(direction_in)), color(color_in), n0(n0_in), n1(n1_in),
+          n2(n2_in), sx(sx_in), sy(sy_in) {}
 };
 
 struct Shader { // shader.h:25-37
@@ -280,7 +289,7 @@ public:
     DeviceScene(const DeviceScene &) = delete;
     DeviceScene &operator=(const DeviceScene &) = delete;
     rt355_scene *handle() const { return h_; }
-    // the global `geo` of main.cpp:557: the direction set of the gather shaders (shading2 / shading3)
+    // the global `geo` (main.cpp:36, filled at main.cpp:639): the direction set of the gather shaders (shading2 / shading3)
     void set_directions(const std::vector<Vector3D> &geo) {
         std::vector<double> xyz;
         for (const Vector3D &g : geo) { xyz.push_back(g.x); xyz.push_back(g.y); xyz.push_back(g.z); }
@@ -332,6 +341,7 @@ inline rt355_stats setPixels(DeviceScene &dev, const Scene &sce, const Shader &s
         rt355_light q; std::memset(&q, 0, sizeof q);
         q.type = l->type; detail::put(q.position, l->position); detail::put(q.direction, l->direction);
         detail::put(q.color, l->color);
+        detail::put(q.n0, l->n0); detail::put(q.n1, l->n1); q.sx = l->sx; q.sy = l->sy;
         ls.push_back(q);
     }
     rt355_shader s; std::memset(&s, 0, sizeof s);

@@ -2,7 +2,7 @@
 // same camera, the four objects it pushes, the directional light it constructs (plus, with
 // `2` as third argument, the point light at light_src2's position), Shader colours of
 // main.cpp:630, alias 0; writes a BMP and a raw RGB8 dump.  With a fifth argument, the path of the OBJ file
-// whose vertices are the gather directions (main.cpp:557 reads "geodesic.obj"), the frame is rendered the
+// whose vertices are the gather directions (main.cpp:639 reads "geodesic.obj"), the frame is rendered the
 // way HEAD of the reference does: CalcSubPixel2 with Shader::shading3 (main.cpp:205,331).
 // With `all` as fifth argument and a BMP file as sixth, the list holds everything main() constructs (its six
 // planes, three spheres -- sphere3 the mirror with the 3D-function texture -- and the textured Environment,

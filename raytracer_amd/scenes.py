@@ -65,6 +65,22 @@ def default_shader(n_lights=1) -> Shader:
     return Shader(default_lights(n_lights), 0x000000, 0xDDDDDD, 0x000000)
 
 
+def area_light(position=(-18.0, -28.0, 42.0), n0=(1.0, 0.0, 0.0), n1=(0.0, 0.6, 0.8), sx=36.0, sy=14.0, color=(1, 1, 1)):
+    """light_src(3, position, direction, color, n0, n1, n2, sx, sy) of light.h:44-54: an area light whose area
+    starts at `position` and spans n0 * sx and n1 * sy (what CalcSoftShadow aims its shadow rays at)."""
+    return light_src(3, position, (0.3, 0.5, -1), color, n0, n1, sx, sy)
+
+
+def soft_shader(kind="area") -> Shader:
+    """Shaders for RT355_SHADING_SOFT.  CalcSoftShadow aims every light's shadow ray at lights[0]'s area
+    (shader.h:441-443): "area" = an area light first, then the directional light of main.cpp:623 and a spot light;
+    "point" = the two lights of default_shader(2), whose constructors leave the unit area of light.h:19-23."""
+    if kind == "point":
+        return default_shader(2)
+    return Shader([area_light(), light_src(0, (-100, -30, 100), (-1, 1, -1), (1, 1, 1)),
+                   light_src(2, (0, -25, 30), (0, 0.6, -1), (1, 0.9, 0.8))], 0x141720, 0xDDDDDD, 0x202020)
+
+
 def default_camera(width, height):
     return camera((0, -20, 0), (0, 1, 0), (0, 0, 1), 10.0, width, height)
 

@@ -31,11 +31,15 @@ def test_library_exports_every_declared_symbol():
     L.rt355_rotation.argtypes = [ctypes.c_uint32] + [ctypes.c_int32] * 4
     for a in ((0, 0, 0, 0, 0), (5, 17, 3, 8, 1), (4_000_000_000, 3839, 2159, 15, 0)):
         assert L.rt355_rotation(*a) == B.rotation(*a)
+    L.rt355_strata.restype = ctypes.c_double
+    L.rt355_strata.argtypes = [ctypes.c_uint32] + [ctypes.c_int32] * 3
+    for a in ((0, 0, 0, 0), (5, 17, 3, 2), (4_000_000_000, 3839, 2159, 1)):
+        assert L.rt355_strata(*a) == B.strata(*a)
 
 
 def test_struct_sizes_match_header_layout():
     from raytracer_amd import binding as B
-    assert B.OBJECT_DTYPE.itemsize == 232 and B.LIGHT_DTYPE.itemsize == 80
+    assert B.OBJECT_DTYPE.itemsize == 232 and B.LIGHT_DTYPE.itemsize == 144
     assert ctypes.sizeof(B.CCamera) == 96 and ctypes.sizeof(B.CStats) == 80
     # ... and what the C compiler makes of the header itself
     import subprocess, tempfile
