@@ -306,12 +306,26 @@ def measure(name, args, ctx):
             return count_rays(st), st
     elif cams is not None:
         mine = frames_for_rank(len(cams), rank, world) if world > 1 else list(range(len(cams)))
+        # A frame is a chain of a dozen dependent launches, so one frame at a time leaves the GPU waiting at every
+        # link; a sweep has many frames to draw, and `in_flight` scene handles, each with its own stream and its own
+        # page-locked pixmap (written by the frame's last kernel itself), keep that many of them going at once.
+        n_fly = max(1, min(args.in_flight, len(mine)))
+        fly = [(r, host, torch.cuda.Stream())] + [(Renderer(scene), HostPixmap(w, h), torch.cuda.Stream()) for _ in range(n_fly - 1)]
+        extra_handles = fly[1:]
 
         def step():
-            rays, st = 0.0, None
-            for f in mine:  # frame f on rank f mod N; every frame moves the camera (the eye's tables are rebuilt)
-                _, st = r.render(cams[f], shader, w, h, mode=mode, shading=shading, out=host.array)
-                rays += count_rays(st)
+            rays, st, busy = 0.0, None, [False] * n_fly
+            for i, f in enumerate(mine):  # frame f on rank f mod N; every frame moves the camera (the eye's tables are rebuilt)
+                rr, hp, s_ = fly[i % n_fly]
+                if busy[i % n_fly]:
+                    st = rr.sync()        # this handle's last frame is complete in its pixmap (here a consumer would take it)
+                    rays += count_rays(st)
+                rr.render_device(cams[f], shader, o, hp.device_ptr, s_.cuda_stream)
+                busy[i % n_fly] = True
+            for k in range(n_fly):
+                if busy[(len(mine) + k) % n_fly]:
+                    st = fly[(len(mine) + k) % n_fly][0].sync()
+                    rays += count_rays(st)
             return rays, st
     else:
         def step():
@@ -337,9 +351,20 @@ def measure(name, args, ctx):
         tmax = torch.tensor([dt], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        rays_all = torch.tensor([rays_step], dtype=torch.float64, device=ctx["reduce_device"])
+        # whole-job ray counts: every rank's share of the step (and, for a frame shared between the ranks, of the frame)
+        keys = ("primary_rays", "shadow_rays", "gather_rays", "secondary_rays", "exact_tests", "overflow_rays", "packet_survivors")
+        rays_all = torch.tensor([rays_step] + [float(stats[k]) for k in keys], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
-        rays_step = float(rays_all.item())
+        rays_step = float(rays_all[0].item())
+        if split:
+            stats = dict(stats, **{k: int(v) for k, v in zip(keys, rays_all[1:].tolist())})
+    if cams is not None:
+        # the frame the sweep ends on lies in the pixmap of the handle that drew it
+        last_host = fly[(len(mine) - 1) % n_fly][1]
+        gpu_last = last_host.array.copy()
+        for rr, hp, _ in extra_handles:
+            rr.close()
+            hp.close()
     if rank != 0:
         r.close()
         host.close()
@@ -362,16 +387,18 @@ def measure(name, args, ctx):
 
     ms_per_step = dt * 1e3 / args.steps
     value = rays_step * args.steps / dt / 1e6
-    gpu_frame = host.array.copy()  # the last frame of the timed region, as the caller of rt355_render received it
+    gpu_frame = gpu_last if cams is not None else host.array.copy()  # the last frame of the timed region, as the caller received it
     fixed_total = split or (cams is not None and world > 1)
     out = {"value": round(value, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4),
            "timed": ("rt355_render_device of this rank's rows + gather of the final frame on rank 0 + its readback" if split else
-                     "rt355_render into a page-locked host pixmap (readback of the frame included)"),
+                     ("rt355_render_device into page-locked host pixmaps, frames in flight on scene handles of their own" if cams is not None else
+                      "rt355_render into a page-locked host pixmap (readback of the frame included)")),
            "scaling": "strong" if fixed_total else "weak",
            "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives,
                       "lights": len(shader.lights), "alias": 0, "shard": shard if (world > 1 or cams is None) else "frames",
-                      "frames_per_step": len(cams) if cams is not None else 1, "search": args.mode,
+                      "frames_per_step": len(cams) if cams is not None else 1,
+                      "frames_in_flight": n_fly if cams is not None else 1, "search": args.mode,
                       "rays_per_frame": {"primary": stats["primary_rays"], "shadow": stats["shadow_rays"],
                                          "gather": stats["gather_rays"], "mirror": stats["secondary_rays"]},
                       "shading": {0: "Shader::shading", 1: "Shader::shading2", 2: "Shader::shading3"}[shading],
@@ -545,6 +572,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--in-flight", type=int, default=2, help="sweep workloads: frames in flight per rank (scene handles)")
     ap.add_argument("--check-launch", action="store_true",
                     help="start the ranks, meet over gloo, print {\"launch\": \"ok\", ...} and stop: no GPU is touched")
     args = ap.parse_args()

@@ -304,6 +304,11 @@ int rt355_render_device_noalloc(rt355_scene *scene, const rt355_camera *cam,
  * of a host copy.  No counterpart in the reference. */
 void *rt355_host_alloc(uint64_t bytes);
 void rt355_host_free(void *p);
+/* The address at which the device reaches a buffer of rt355_host_alloc (NULL for any other pointer): passed to
+ * rt355_render_device as d_pixmap it makes the frame arrive in host memory without a copy and without the call
+ * waiting for it -- several scene handles, each on its own stream, then keep several frames of a camera sweep in
+ * flight, and rt355_scene_sync(handle) tells when a handle's frame is complete. */
+void *rt355_host_device_pointer(void *p);
 
 /* Wait for the scene's outstanding render and fill the stats passed to it. */
 int rt355_scene_sync(rt355_scene *scene);

@@ -8,8 +8,11 @@
  * HIP library never links or calls anything in this file.
  *
  * Parity pin: oracle/ref_harness.cpp compiles the reference's own headers and compares
- * (tests/golden/ holds the derived vectors); the three frame hashes the reference
- * main.cpp path produced are checked in tests/test_oracle_golden.py.
+ * (tests/golden/ holds the derived vectors: frames, CalcIntersect values, the Color operator
+ * table, texture lookups); 18 pixel values recorded from a run of the reference's main.cpp and
+ * the hashes of the default scene's 800x600 and 3840x2160 frames (b5fabdf4953d0714,
+ * 6647a8b414e21d93, b7bc333b9d9ae34d: what a build of main.cpp itself was measured to render)
+ * are checked in tests/test_oracle_golden.py.
  *
  * Every function cites the reference lines (relative to image_synthesis/) it follows.
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (no -ffast-math: the

@@ -47,6 +47,8 @@ def lib():
         L.rt355_host_alloc.argtypes = [C.c_uint64]
         L.rt355_host_free.restype = None
         L.rt355_host_free.argtypes = [C.c_void_p]
+        L.rt355_host_device_pointer.restype = C.c_void_p
+        L.rt355_host_device_pointer.argtypes = [C.c_void_p]
         L.rt355_scene_sync.argtypes = [C.c_void_p]
         L.rt355_scene_search_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.rt355_scene_resolve_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -169,6 +171,8 @@ class HostPixmap:
         if not self.ptr:
             raise Rt355Error("rt355_host_alloc failed")
         self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(self.ptr)).reshape(height, width, 3)
+        # where kernels reach it: what rt355_render_device takes to render straight into this pixmap
+        self.device_ptr = lib().rt355_host_device_pointer(self.ptr)
 
     def close(self):
         if self.ptr:

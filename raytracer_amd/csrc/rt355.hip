@@ -1648,6 +1648,9 @@ __device__ __forceinline__ void direct_store(unsigned char *__restrict__ pixmap,
         if (valid) w.rec_sum[xy_to_rid(x, y, f.tiles_x)] = clr;
         return;
     }
+    // (the four waves of a workgroup store together: their 768 bytes then leave the L2 as whole lines -- without
+    // the barrier the counters see 1.5 times the frame written)
+    __syncthreads();
     store_row_segment<DIRECT_SEG>(pixmap, f, x, y, valid, clr);
 }
 // CalcPixel's average over the alias x alias sub-samples of a pixel (main.cpp:315-325): sums of the
@@ -3917,6 +3920,11 @@ extern "C" void *rt355_host_alloc(uint64_t bytes) {
     return p;
 }
 extern "C" void rt355_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" void *rt355_host_device_pointer(void *p) {
+    void *mapped = nullptr;
+    if (!p || hipHostGetDevicePointer(&mapped, p, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return mapped;
+}
 
 static bool host_is_pinned(const void *p) { // page-locked memory the runtime knows (hipHostMalloc, hipHostRegister)
     hipPointerAttribute_t attr;

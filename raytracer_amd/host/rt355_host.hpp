@@ -135,67 +135,100 @@ struct Triangle { // anyobject.h:444-532 (data members only)
     void SetUV(Vector2D t0, Vector2D t1, Vector2D t2) { UV_p0 = t0; UV_p1 = t1; UV_p2 = t2; }
 };
 
+// ---- OBJ files, read the way Mesh::Mesh reads them (anyobject.h:546-644) ------------------------------------
+// What the reference's reader does, as rules: a line is told by its first two characters ("v ", "vt", "vn", "f ",
+// anything else is skipped); numbers are taken from a line as operator>> takes them (the leading ones that parse,
+// 0 for the rest); a face line is matched against one of three layouts with sscanf and "%i" (so 0x.. and 0..
+// prefixes count), and only its first three corners are used; the layout in use starts as the simplest and moves
+// on to the next when a line does not fit -- for good; a face line that fits no layout ends the reading with what
+// was read so far; a file that cannot be opened reads as empty.
+namespace objfile {
+struct Corner { int vertex = 1, uv = 1, normal = 1; }; // 1-based; 1 where the layout has no such field (:597-599)
+struct FaceLayout { const char *pattern; int per_corner; };
+static const FaceLayout kLayouts[3] = {
+    {"f %i %i %i", 1},                       // anyobject.h:603
+    {"f %i/%i %i/%i %i/%i", 2},              // :610
+    {"f %i/%i/%i %i/%i/%i %i/%i/%i", 3},     // :617
+};
+inline bool scan_face(const std::string &line, const FaceLayout &lay, Corner corner[3]) {
+    int field[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+    const int got = std::sscanf(line.c_str(), lay.pattern, &field[0], &field[1], &field[2], &field[3], &field[4], &field[5],
+                                &field[6], &field[7], &field[8]);
+    if (got != 3 * lay.per_corner) return false;
+    for (int c = 0; c < 3; c++) {
+        const int *f = field + c * lay.per_corner;
+        corner[c] = Corner();
+        corner[c].vertex = f[0];
+        if (lay.per_corner >= 2) corner[c].uv = f[1];
+        if (lay.per_corner >= 3) corner[c].normal = f[2];
+    }
+    return true;
+}
+inline void leading_numbers(const std::string &text, double *out, int count) {
+    for (int i = 0; i < count; i++) out[i] = 0;
+    std::istringstream in(text);
+    for (int i = 0; i < count && (in >> out[i]); i++) {}
+}
+// Calls on_line(kind, rest) for every line of the file, kind = the line's first two characters; stops when
+// on_line returns false.  Returns false if the file cannot be opened.
+template <class OnLine>
+inline bool for_each_line(const std::string &path, OnLine on_line) {
+    std::ifstream in(path.c_str());
+    if (in.fail()) return false;
+    std::string line;
+    while (in.peek() != EOF) {
+        std::getline(in, line);
+        if (!on_line(line.substr(0, 2), line)) break;
+    }
+    return true;
+}
+} // namespace objfile
+
 class Mesh : public AnyObject { // anyobject.h:534-675
 public:
     Color clr{150, 200, 110};
     std::vector<Triangle> triangles;
     explicit Mesh(std::vector<Triangle> tris = {}, double ks_in = 0) : triangles(std::move(tris)) { ks = ks_in; }
-    // Mesh(string filePath, Point3D mesh_origin, double scale, double ks) of anyobject.h:546-644, line by line:
-    // `v` lines become mesh_origin + (p - 0) * scale, `vt` lines texture coordinates, `vn` lines are counted
-    // (vertex normals are stored by the reference and used nowhere on the path), `f` lines are read with
-    // sscanf as `a b c`, then `a/p b/q c/r`, then `a/p/l b/q/m c/r/n` -- the format escalates when a line does
-    // not fit and never goes back; only the first three corners of a face are used; a face that fits none of
-    // the formats ends the reading with what was read so far, and a file that cannot be opened gives an
-    // empty mesh (the reference reports both on cout and carries on).  An index outside the lists read so
-    // far is undefined behaviour there and an Error here.
+    // Mesh(string filePath, Point3D mesh_origin, double scale, double ks) of anyobject.h:546-644: vertices become
+    // mesh_origin + (p - 0) * scale (:575); a face takes its texture coordinates only if a `vt` line came before it
+    // (:631), vertex normals are counted and used nowhere on the path.  An index outside the lists read so far is
+    // undefined behaviour in the reference and an Error here.
     explicit Mesh(const std::string &filePath, Point3D mesh_origin = Point3D(0, 0, 0), double scale = 1, double ks_in = 0) {
         ks = ks_in;
-        std::ifstream ifs(filePath.c_str());
-        if (ifs.fail()) return;
         std::vector<Point3D> vertices;
-        std::vector<Vector2D> UVs;
+        std::vector<Vector2D> uvs;
         size_t n_normals = 0;
-        std::string line;
-        int face_type = 1;
-        bool has_normal = false, has_texture = false;
-        while (ifs.peek() != EOF) {
-            std::getline(ifs, line);
-            if (line.substr(0, 2) == "v ") {
-                std::istringstream v(line.substr(2));
-                double x = 0, y = 0, z = 0;
-                v >> x; v >> y; v >> z;
-                vertices.push_back(Point3D(mesh_origin.x + (x - 0) * scale, mesh_origin.y + (y - 0) * scale,
-                                           mesh_origin.z + (z - 0) * scale));
-            } else if (line.substr(0, 2) == "vt") {
-                has_texture = true;
-                std::istringstream v(line.substr(2));
-                double x = 0, y = 0;
-                v >> x; v >> y;
-                UVs.push_back(Vector2D(x, y));
-            } else if (line.substr(0, 2) == "vn") {
-                has_normal = true;
+        int layout = 0; // index into objfile::kLayouts, only ever grows
+        auto listed = [](int index, size_t size) { return index >= 1 && (size_t)index <= size; };
+        objfile::for_each_line(filePath, [&](const std::string &kind, const std::string &line) {
+            double num[3];
+            if (kind == "v ") {
+                objfile::leading_numbers(line.substr(2), num, 3);
+                vertices.push_back(Point3D(mesh_origin.x + (num[0] - 0) * scale, mesh_origin.y + (num[1] - 0) * scale,
+                                           mesh_origin.z + (num[2] - 0) * scale));
+            } else if (kind == "vt") {
+                objfile::leading_numbers(line.substr(2), num, 2);
+                uvs.push_back(Vector2D(num[0], num[1]));
+            } else if (kind == "vn") {
                 n_normals++;
-            } else if (line.substr(0, 2) == "f ") {
-                int a = 1, b = 1, c = 1, p = 1, q = 1, r = 1, l = 1, m = 1, n = 1;
-                const char *chh = line.c_str();
-                if (face_type == 1 && std::sscanf(chh, "f %i %i %i", &a, &b, &c) != 3) face_type = 2;
-                if (face_type == 2 && std::sscanf(chh, "f %i/%i %i/%i %i/%i", &a, &p, &b, &q, &c, &r) != 6) face_type = 3;
-                if (face_type == 3 && std::sscanf(chh, "f %i/%i/%i %i/%i/%i %i/%i/%i", &a, &p, &l, &b, &q, &m, &c, &r, &n) != 9)
-                    return;
-                auto in = [](int i, size_t size) { return i >= 1 && (size_t)i <= size; };
-                if (!in(a, vertices.size()) || !in(b, vertices.size()) || !in(c, vertices.size()))
-                    throw Error(filePath + ": face refers to a vertex that was not read: " + line);
-                Triangle tri(vertices[a - 1], vertices[b - 1], vertices[c - 1]);
-                if (has_normal && (!in(l, n_normals) || !in(m, n_normals) || !in(n, n_normals)))
-                    throw Error(filePath + ": face refers to a normal that was not read: " + line);
-                if (has_texture) {
-                    if (!in(p, UVs.size()) || !in(q, UVs.size()) || !in(r, UVs.size()))
+            } else if (kind == "f ") {
+                objfile::Corner c[3];
+                while (layout < 3 && !objfile::scan_face(line, objfile::kLayouts[layout], c)) layout++;
+                if (layout == 3) return false; // fits no layout: the reading ends here (:618-621)
+                for (int k = 0; k < 3; k++) {
+                    if (!listed(c[k].vertex, vertices.size()))
+                        throw Error(filePath + ": face refers to a vertex that was not read: " + line);
+                    if (n_normals && !listed(c[k].normal, n_normals))
+                        throw Error(filePath + ": face refers to a normal that was not read: " + line);
+                    if (!uvs.empty() && !listed(c[k].uv, uvs.size()))
                         throw Error(filePath + ": face refers to a texture coordinate that was not read: " + line);
-                    tri.SetUV(UVs[p - 1], UVs[q - 1], UVs[r - 1]);
                 }
+                Triangle tri(vertices[c[0].vertex - 1], vertices[c[1].vertex - 1], vertices[c[2].vertex - 1]);
+                if (!uvs.empty()) tri.SetUV(uvs[c[0].uv - 1], uvs[c[1].uv - 1], uvs[c[2].uv - 1]);
                 triangles.push_back(tri);
             }
-        }
+            return true;
+        });
     }
     const std::string GetObjectType() const override { return "Mesh"; }
 };
@@ -299,30 +332,24 @@ private:
     rt355_scene *h_ = nullptr;
 };
 
-// Geodesic(string filePath) of main.cpp:408-450: the `v x y z` lines of an OBJ file, minus their mean,
-// normalised.  A file that cannot be opened gives an empty set, as there (every hit then renders black).
+// Geodesic(string filePath) of main.cpp:408-450: the `v x y z` lines of an OBJ file, moved so that their mean is
+// the origin and normalised (:443-447, in that operation order).  A file that cannot be opened gives an empty set,
+// as there (every hit then renders black).
 inline std::vector<Vector3D> Geodesic(const std::string &filePath) {
     std::vector<Vector3D> geo;
-    std::ifstream ifs(filePath.c_str());
-    if (ifs.fail()) return geo;
-    std::string line;
-    Vector3D sum(0, 0, 0);
-    int cnt = 0;
-    while (ifs.peek() != EOF) {
-        std::getline(ifs, line);
-        if (line.substr(0, 2) != "v ") continue;
-        std::istringstream v(line.substr(2));
-        double x = 0, y = 0, z = 0;
-        v >> x; v >> y; v >> z;
-        geo.push_back(Vector3D(x, y, z));
-        sum = Vector3D(sum.x + x, sum.y + y, sum.z + z);
-        cnt++;
-    }
-    sum = Vector3D(sum.x / cnt, sum.y / cnt, sum.z / cnt);
-    for (Vector3D &g : geo) {
-        Vector3D d(0 - sum.x, 0 - sum.y, 0 - sum.z); // Point3D(0, 0, 0) - sum, main.cpp:446
-        g = Normalize(Vector3D(g.x + d.x, g.y + d.y, g.z + d.z));
-    }
+    double total[3] = {0, 0, 0};
+    objfile::for_each_line(filePath, [&](const std::string &kind, const std::string &line) {
+        if (kind != "v ") return true;
+        double num[3];
+        objfile::leading_numbers(line.substr(2), num, 3);
+        geo.push_back(Vector3D(num[0], num[1], num[2]));
+        for (int a = 0; a < 3; a++) total[a] = total[a] + num[a];
+        return true;
+    });
+    const double count = (double)(int)geo.size();
+    const Vector3D mean(total[0] / count, total[1] / count, total[2] / count);
+    const Vector3D shift(0 - mean.x, 0 - mean.y, 0 - mean.z); // Point3D(0, 0, 0) - sum, main.cpp:446
+    for (Vector3D &g : geo) g = Normalize(Vector3D(g.x + shift.x, g.y + shift.y, g.z + shift.z));
     return geo;
 }
 

@@ -114,10 +114,36 @@ def test_camera_sweep_of_the_triangle_scene(api, oracle):
     packed = scene.pack()
     r = api.Renderer(packed)
     host = api.HostPixmap(w, h)
-    for f in frames_for_rank(60, 3, 8)[:5]:  # what rank 3 of 8 renders: 3, 11, 19, 27, 35
+    mine = frames_for_rank(60, 3, 8)[:5]  # what rank 3 of 8 renders: 3, 11, 19, 27, 35
+    frames, rays = {}, {}
+    for f in mine:
         _, st = r.render(cams[f], sh, w, h, out=host.array)
         assert st["primary_hits"] > w * h // 4
         _sample_equal(host.array, oracle, packed, cams[f], sh, w, h, 32)
+        frames[f], rays[f] = host.array.copy(), st["shadow_rays"]
+    # the same frames, two in flight: two scene handles, each on a stream of its own, render straight into their
+    # page-locked pixmaps (rt355_render_device with the pixmap's device address) while the other one is still busy
+    import torch
+    fly = [(r, host, torch.cuda.Stream()), (api.Renderer(packed), api.HostPixmap(w, h), torch.cuda.Stream())]
+    pending = [None, None]
+
+    def finish(k):
+        st = fly[k][0].sync()
+        f = pending[k]
+        assert np.array_equal(fly[k][1].array, frames[f]) and st["shadow_rays"] == rays[f], f
+        pending[k] = None
+    for i, f in enumerate(mine):
+        k = i % 2
+        if pending[k] is not None:
+            finish(k)
+        fly[k][1].array[:] = 0
+        fly[k][0].render_device(cams[f], sh, B.opts(w, h), fly[k][1].device_ptr, fly[k][2].cuda_stream)
+        pending[k] = f
+    for k in (0, 1):
+        if pending[k] is not None:
+            finish(k)
+    fly[1][0].close()
+    fly[1][1].close()
     host.close()
     r.close()
 
