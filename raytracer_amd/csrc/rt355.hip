@@ -1811,13 +1811,14 @@ __device__ __forceinline__ SoftArgs soft_args(const Frame &f, int gx, int gy) {
 // SOFT: CalcSoftShadow (shader.h:439-483) in place of CalcShadow -- the shadow ray aims at the point
 // lights[0].position + n0 * sx * m + n1 * sy * n of lights[0]'s area whichever light is being shaded (:441-443), the
 // facing test takes the vector to that point as it is (:445-446), L stays the distance to light k's position (:462).
-template <bool SOFT = false, class Occluder>
+// SKIP: leave out the highlight and the shadow mix where they change nothing (see calc_specular, shadow_mix).
+template <bool SOFT = false, bool SKIP = false, class Occluder>
 __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, const HitRec &h, uint32_t sum,
                                                 Occluder occluder, uint32_t &n_shadow, double soft_m = 0, double soft_n = 0) {
     const DLight &L = sh.lights[k];
     const d3 nhl = light_nhl(L, h.ph);
     uint32_t clr = calc_diffuse(L, h.cm0, h.cm1, h.nh, nhl);
-    clr = calc_specular(sh, L, clr, h.reh, nhl);
+    clr = calc_specular<SKIP>(sh, L, clr, h.reh, nhl);
     if (!h.no_border) clr = calc_border(sh, clr, h.border_w);
     double shd = 0.5; // shader.h:396-398
     if (SOFT) {
@@ -1840,7 +1841,7 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
         shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
         n_shadow += 1;
     }
-    clr = shadow_mix(sh, L, clr, nhl, shd);
+    clr = shadow_mix<SKIP>(sh, L, clr, nhl, shd);
     return light_mean(sum, clr, k);
 }
 
@@ -1889,7 +1890,7 @@ __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneVie
             ph = h.ph; nh = h.nh; obj = h.obj;
             if (h.emissive) sum = h.cm0;
             for (int k = 0; !h.emissive && k < sh.n_lights; k++)
-                sum = shade_light<SOFT>(sh, k, h, sum, [&](const Ray &sr) {
+                sum = shade_light<SOFT, true>(sh, k, h, sum, [&](const Ray &sr) {
                     Closest o;
                     closest_hit<false, ENV>(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
                     return o.t_best;
@@ -2037,7 +2038,7 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
                 ph = h.ph; nh = h.nh; oi = h.obj;
                 if (h.emissive) own = h.cm0;
                 for (int k = 0; !h.emissive && k < sh.n_lights; k++)
-                    own = shade_light<SOFT>(sh, k, h, own, [&](const Ray &sr) {
+                    own = shade_light<SOFT, true>(sh, k, h, own, [&](const Ray &sr) {
                         Closest o;
                         closest_hit(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
                         return o.t_best;
@@ -2621,7 +2622,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     // (the rays of the levels after the camera rays' are cast by the recursion, which passes neither m nor n)
     const SoftArgs soft = (SOFT && f.level <= 0) ? soft_args(f, x, y) : SoftArgs{0, 0.0, 0.0};
     for (int g = 0; g < cur.count; g++) {
-        sum = shade_light<SOFT>(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
+        sum = shade_light<SOFT, false>(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
             Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_STRIDE(n); sp.count = w.spill.count + g;
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;

@@ -42,9 +42,22 @@ __device__ __forceinline__ d3 normalize(d3 v) { // :79-88
 // Color(char,char,char) (color.h:25) fed with a double: x86-64 converts with cvttsd2si to 32
 // bits and keeps the low byte -- toward zero, wrap mod 256, out of range or NaN -> 0.
 // v_cvt_i32_f64 saturates instead, hence the explicit range test.
+// v_cvt_i32_f64 truncates toward zero, saturates out-of-range values and turns NaN into 0.  Saturated at the negative
+// end it gives 0x80000000, x86's own answer for everything it cannot represent (low byte 0), so only the positive
+// end needs a test: from 2^31 up (and for NaN, where the comparison fails) the byte is 0, not the 0xff of INT_MAX.
+// (The instruction is written out because a C cast of an out-of-range double is undefined to the compiler.)
+__device__ __forceinline__ int32_t cvt_i32_saturating(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t i;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(i) : "v"(x));
+    return i;
+#else
+    return (x > -2147483649.0 && x < 2147483648.0) ? (int32_t)x : (x < 0 ? INT32_MIN : (x == x ? INT32_MAX : 0));
+#endif
+}
 __device__ __forceinline__ uint32_t q8(double x) {
-    if (!(x > -2147483649.0 && x < 2147483648.0)) return 0u;
-    return (uint32_t)(int32_t)x & 0xffu;
+    const uint32_t low = (uint32_t)cvt_i32_saturating(x) & 0xffu;
+    return (x < 2147483648.0) ? low : 0u;
 }
 // colours travel as 0x00BBGGRR in one register
 __device__ __forceinline__ uint32_t RGB(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); }
@@ -64,8 +77,8 @@ __device__ __forceinline__ uint32_t cadd(uint32_t a, uint32_t b) { // :45, each 
     return RGB((cr(a) + cr(b)) & 0xffu, (cg(a) + cg(b)) & 0xffu, (cb(a) + cb(b)) & 0xffu);
 }
 __device__ __forceinline__ int trunc_i32(double x) { // the reference's (int)x casts, texture.h:92-97
-    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int)0x80000000;
-    return (int32_t)x;
+    const int32_t i = cvt_i32_saturating(x);
+    return (x < 2147483648.0) ? i : (int)0x80000000;
 }
 
 // ---- device scene records --------------------------------------------------------------------
@@ -143,14 +156,17 @@ __device__ __forceinline__ double sphere_t(const DObject &o, const Ray &e, int *
     if (delta < 0) return -1;
     return B - (double)outside * sqrt(delta);
 }
-// the same on a (centre, radius) record
+// the same on a (centre, radius) record, for callers that only ask whether t >= 0 and how large it is: with the
+// origin outside and the centre behind it (B < 0) the root B - sqrt(delta) is negative whatever delta is, so the
+// square root is not taken (any negative value stands for a miss there)
 __device__ __forceinline__ double sphere_t_rec(const double4 &q, const Ray &e) {
     d3 c = D3(q.x, q.y, q.z);
     double r = q.w;
     d3 ec = vsub(e.pe, c);
-    int outside = (dot(ec, ec) - r * r <= -0.00001) ? -1 : 1;
-    double B = dot(e.npe, vsub(c, e.pe));
     double Cc = dot(ec, ec) - r * r;
+    int outside = (Cc <= -0.00001) ? -1 : 1;
+    double B = dot(e.npe, vsub(c, e.pe));
+    if (outside > 0 && B < 0) return -1;
     double delta = B * B - Cc;
     if (delta < 0) return -1;
     return B - (double)outside * sqrt(delta);
@@ -548,10 +564,15 @@ __host__ __device__ __forceinline__ void sincos_rounded(double x, double *sin_ou
 __device__ __forceinline__ d3 mirror_dir(d3 nh, d3 npe) {
     return normalize(vsub(npe, vmul(nh, 2 * dot(nh, npe))));
 }
-// CalcSpecular, shader.h:340-376 (SpecularType 0)
+// CalcSpecular, shader.h:340-376 (SpecularType 0).  SKIP: without a highlight (s <= 0) return clr as it is -- 0^25 = 0,
+// and clr * 1 + specular * 0 is clr itself, channel by channel; a spot light's factor could still turn the 0 into a
+// NaN, so that case takes the long way.  (The one-kernel renderers save a tenth of their time with it; in the
+// shading kernel of the searched path, which runs at its register limit, the extra branch costs more than it saves.)
+template <bool SKIP = false>
 __device__ __forceinline__ uint32_t calc_specular(const ShaderView &sh, const DLight &L, uint32_t clr, d3 reh,
                                                   d3 nhl) {
     double s = dot(vmul(nhl, -1), reh);
+    if (SKIP && !(s > 0) && L.type != 2) return clr;
     s = (s > 0) ? s : 0;
     s = RT_POW25(s);
     if (L.type == 2) s = s * spot_factor(L, nhl);
@@ -568,10 +589,13 @@ __device__ __forceinline__ double border_weight(d3 pe, d3 ph, d3 nh) {
 __device__ __forceinline__ uint32_t calc_border(const ShaderView &sh, uint32_t clr, double b) {
     return cadd(cmul(clr, 1 - b), cmul(sh.border, b));
 }
-// tail of CalcShadow, shader.h:412-432, given the closest occluder distance
+// tail of CalcShadow, shader.h:412-432, given the closest occluder distance (SKIP: a lit point keeps its colour,
+// clr * 1 + ambient * 0 is clr itself)
+template <bool SKIP = false>
 __device__ __forceinline__ uint32_t shadow_mix(const ShaderView &sh, const DLight &L, uint32_t clr, d3 nhl,
                                                double shd) {
     if (L.type == 2) shd = shd * spot_factor(L, nhl);
+    else if (SKIP && shd == 1.0) return clr;
     return cadd(cmul(clr, shd), cmul(sh.ambient, 1 - shd));
 }
 // running mean over lights, shader.h:93: clr_sum / (k+1) * k + clr / (k+1) on Color, i.e. per channel
