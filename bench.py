@@ -73,6 +73,19 @@ def build_workload(name: str):
             elif i % 3 == 0:
                 o["ks"] = 0.9 if i % 9 == 0 else 0.5
         return sc, S.spheres_shader(8), S.default_camera(w, h), w, h
+    if name == "spheres10k_glass_8lights_4k":
+        # refraction on a scene of many primitives: every tenth sphere of the spheres scene of glass (some of them
+        # mirrors too), the whole inside an Environment so that every ray ends somewhere (main.cpp:116-154)
+        w, h = 3840, 2160
+        sc = S.spheres_scene(10000, seed=355)
+        for i, o in enumerate(sc.objects):
+            if i and i % 10 == 0:
+                o["fresnel"] = 0.3 if i % 20 else 0.6
+                o["ior"] = 1.5 if i % 30 else 1.2
+                if i % 40 == 0:
+                    o["ks"] = 0.4
+        sc.add_environment((0, 60, 10), 600, (110, 150, 235))
+        return sc, S.spheres_shader(8), S.default_camera(w, h), w, h
     if name == "default_mirrors_4k":  # the reference's scene with reflecting objects (main.cpp:93-112), unsearched
         w, h = 3840, 2160
         sc, sh, _, _, _ = S.small_case("mirrors")
@@ -518,7 +531,7 @@ def measure(name, args, ctx):
 
 HEADLINE = "default_4k"
 OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "mesh100k_sweep60", "default_bleed162_4k",
-          "spheres10k_mirrors_8lights_4k", "glass_room_4k"]
+          "spheres10k_mirrors_8lights_4k", "glass_room_4k", "spheres10k_glass_8lights_4k"]
 
 
 def spawn_ranks(n: int) -> int:

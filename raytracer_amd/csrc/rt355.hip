@@ -2000,20 +2000,47 @@ __device__ __forceinline__ void intersect_inside(const SceneView &s, int obj, co
     // mesh then drops (t_min > 0, :659): always the miss tuple, point and normal zero (:664)
     *ph_out = ph; *nh_out = nh;
 }
+// The closest hit of one ray found by its thread alone through the scene table (the walk k_search_general's lanes
+// do, see walk_ray): the candidates go to the thread's own slots of workspace slot 0 -- planes, environments and
+// quadrics first, they are candidates of every ray -- and the fp64 tests take them from there.  A ray the table
+// cannot answer for (no finite unit direction, an origin far from the scene) is tested against everything.
+template <bool ENV>
+__device__ __forceinline__ void closest_hit_walk(const SceneView &s, const GeneralTable &t, const Ray &e, uint32_t rid,
+                                                 const Work &w, Closest &c, uint32_t &evaluated, uint32_t &overflowed,
+                                                 uint32_t &n_pairs) {
+    const float ox = (float)e.pe.x, oy = (float)e.pe.y, oz = (float)e.pe.z;
+    const float ux = (float)e.npe.x, uy = (float)e.npe.y, uz = (float)e.npe.z;
+    const float ul = ux * ux + uy * uy + uz * uz, o_l1 = fabsf(ox) + fabsf(oy) + fabsf(oz);
+    if (!(ul > 0.99f && ul < 1.01f) || !(o_l1 < t.far_origin)) {
+        closest_hit<false, ENV>(s, e, true, rid, w.n, w.cand, w.cand_cnt, w.spill, c, evaluated, overflowed);
+        return;
+    }
+    uint32_t cnt = 0;
+    for (int p = 0; p < t.n_planes; p++) append_id(t.plane_id[p], rid, w.n, w.cand, cnt, w.spill);
+    walk_ray(t, ox, oy, oz, ux, uy, uz, o_l1, rid, w.n, w.cand, cnt, w.spill, n_pairs);
+    w.cand_cnt[rid] = cnt;
+    closest_hit<false, ENV>(s, e, false, rid, w.n, w.cand, w.cand_cnt, w.spill, c, evaluated, overflowed);
+}
 // (three waves per SIMD: at the two the compiler picks by itself the frame takes 30 % longer, at four the spills cost more)
-template <bool SOFT>
+// WALK: a scene of many primitives -- every ray of the pixel's tree, shadow rays included, finds its candidates
+// through the scene table (closest_hit_walk) instead of testing every primitive.
+template <bool SOFT, bool WALK>
 __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
-                                                        unsigned char *__restrict__ pixmap) {
-    const uint32_t rid = 0; // (no per-ray lists on this path)
-    uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0, n_deep = 0;
+                                                        GeneralTable table, unsigned char *__restrict__ pixmap) {
+    uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0, n_deep = 0, n_pairs = 0;
     int x, y;
     direct_xy(f, &x, &y);
     const bool valid = x < f.grid_w && y < f.grid_h;
+    const uint32_t rid = (WALK && valid) ? xy_to_rid(x, y, f.tiles_x) : 0u; // the thread's slots of the per-ray lists
     uint32_t pixel = 0u;
     do {
     if (!valid) break;
     Ray e = grid_ray(cam, f, x, y);
     Spill none; none.pool = nullptr; none.count = nullptr;
+    auto closest = [&](const Ray &ray, Closest &out) {
+        if (WALK) closest_hit_walk<true>(s, table, ray, rid, w, out, n_eval, n_over, n_pairs);
+        else closest_hit(s, ray, true, rid, f.n_rays, nullptr, nullptr, none, out, n_eval, n_over);
+    };
     uint32_t op_clr[REFRACT_OPS], op_what[REFRACT_OPS]; // what = object | kind << 30
     RefractSpawn spawn[REFRACT_SPAWNS];
     int n_ops = 0, n_spawn = 0;
@@ -2031,7 +2058,7 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
             intersect_inside(s, oi, e, outside, &ph, &nh);
         } else {
             Closest c;
-            closest_hit(s, e, true, rid, f.n_rays, nullptr, nullptr, none, c, n_eval, n_over);
+            closest(e, c);
             if (c.prim_best >= 0) {
                 if (first) n_hit = 1;
                 const HitRec h = primary_record(s, sh, e, c);
@@ -2040,7 +2067,7 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
                 for (int k = 0; !h.emissive && k < sh.n_lights; k++)
                     own = shade_light<SOFT, true>(sh, k, h, own, [&](const Ray &sr) {
                         Closest o;
-                        closest_hit(s, sr, true, rid, f.n_rays, nullptr, nullptr, none, o, n_eval, n_over);
+                        closest(sr, o);
                         return o.t_best;
                     }, n_shadow, first ? soft.m : 0.0, first ? soft.n : 0.0);
             }
@@ -2136,6 +2163,7 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
     wave_count(w.counters, 2, n_over);
     wave_count(w.counters, 6, n_secondary);
     wave_count(w.counters, 14, n_deep);
+    if (WALK) wave_count(w.counters, 5, n_pairs);
 }
 
 // CalcSubPixel2 (main.cpp:163-209), the renderer HEAD of the reference selects: the closest hit as in
@@ -3647,8 +3675,14 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
 #undef LAUNCH_GATHER
 #define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
         else if (refract) {
-            if (soft) hipLaunchKernelGGL(k_render_refract<true>, dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
-            else hipLaunchKernelGGL(k_render_refract<false>, dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
+            // scenes of many primitives find their candidates through the scene table (not in mode BRUTE, and not
+            // from the entry point that has no workspace)
+            const bool walk = sc->has_general && sc->view.n_prims >= SEARCH_MIN_PRIMS && opts->mode != RT355_MODE_BRUTE && !noalloc;
+            if (walk) HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
+#define LAUNCH_REFRACT(S, W) hipLaunchKernelGGL((k_render_refract<S, W>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix)
+            if (soft) { if (walk) LAUNCH_REFRACT(true, true); else LAUNCH_REFRACT(true, false); }
+            else { if (walk) LAUNCH_REFRACT(false, true); else LAUNCH_REFRACT(false, false); }
+#undef LAUNCH_REFRACT
         } else if (soft) {
             hipLaunchKernelGGL((k_render_direct<true, true, true>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix);
         } else if (sc->reflective) {

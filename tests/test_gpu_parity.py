@@ -661,6 +661,40 @@ def test_random_glass_in_a_room(api, oracle, seed):
 
 
 @pytest.mark.gpu
+def test_glass_among_many_spheres(api, oracle):
+    """Refraction where the scene is searched: 1 500 spheres, every tenth of glass, some of those mirrors too, under
+    three lights inside an Environment.  The searched modes walk the scene table for every ray of a pixel's tree
+    (camera, mirror, refracted and shadow rays); BRUTE tests every primitive.  Frames and ray counts against the
+    checker, supersampled and in row tiles as well."""
+    sc = S.spheres_scene(1500, seed=97)
+    for i, o in enumerate(sc.objects):
+        if i and i % 10 == 0:
+            o["fresnel"] = 0.3 if i % 20 else 0.6
+            o["ior"] = 1.5 if i % 30 else 1.2
+            if i % 40 == 0:
+                o["ks"] = 0.4
+    sc.objects[0]["ks"] = 0.3
+    sc.add_environment((0, 60, 10), 600, (110, 150, 235))
+    sh = S.Shader(S.ring_lights(3), 0x101010, 0xDDDDDD, 0x202020)
+    w, h = 160, 120
+    cam = S.default_camera(w, h)
+    r = api.Renderer(sc)
+    for alias in (0, 2):
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, alias=alias, seed=8), threads=0)
+        assert wst["secondary_rays"] > w * h // 50
+        for mode in (B.MODE_PACKET, B.MODE_ALLPAIRS, B.MODE_BRUTE):
+            got, st = r.render(cam, sh, w, h, alias=alias, seed=8, mode=mode)
+            _compare(got, want)
+            assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"], (alias, mode)
+            assert (st["pair_tests"] > 0) == (mode != B.MODE_BRUTE)   # the table was walked
+    got = np.zeros_like(want)
+    for g in range(3):
+        r.render(cam, sh, w, h, alias=2, seed=8, out=got, tile_rows=16, tile_count=3, tile_phase=g)
+    _compare(got, want)
+    r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(60, 66))
 def test_random_scenes_with_textures(api, oracle, seed):
     """The random scenes with texture mapping (type 1), solid textures with random projectors (type 2) and the
