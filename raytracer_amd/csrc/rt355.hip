@@ -181,6 +181,10 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     double *ktotal;       // reflection_ktotal after the deepest level so far
     uint32_t *deepest;    // deepest level the chain of this sub-sample reached
     double *ray_d;        // [6] the ray of the level being traced: pe.xyz, npe.xyz
+    // the gather shaders on searched scenes (allocated when such a frame is rendered), see k_gather_init
+    uint16_t *g_slot;           // [cells * per_cell][n] the direction a hit sends in this pass, 0xffff = none
+    unsigned long long *g_left; // [ceil(dirs / 64)][n] the directions of a hit that found no place in its cell
+    uint32_t *g_count;          // [cells * per_cell + dirs] rays of each pass
 };
 
 // Kernels that work on the rays of several lights at once take the workspace slot from blockIdx.y
@@ -1247,7 +1251,9 @@ struct GeneralTable {
     const float4 *chunk;     // [n_supers * 64] bounding sphere of prim[64 j .. 64 j + 63]
     const float4 *super;     // [n_supers] bounding sphere of chunk[64 k .. 64 k + 63]
     const uint32_t *plane_id;// [n_planes] candidate ids of the planes
-    int32_t n_supers, n_planes;
+    const uint4 *nodes;      // the 8-ary tree of walk_ray over `prim`: levels 0 .. n_lvls - 1, node k of level L is
+                             // child (level_offset(L) + k) % 8 of the 64-byte group (level_offset(L) + k) / 8
+    int32_t n_supers, n_planes, n_lvls;
     float tight_rho, tight_theta; // a wave whose origin ball and cone are within these searches as one beam
     float far_origin;             // SceneView::far_origin
 };
@@ -1266,15 +1272,16 @@ __device__ __forceinline__ bool beam_meets(const Beam &b, const float4 &q) {
     return ang <= b.theta + asinf(reach * inv) + 2e-5f;
 }
 // may the ray (o, u) hit the sphere q?
+// (t_limit: the ray is only of interest up to there; the sphere is entered no earlier than along - reach)
 __device__ __forceinline__ bool ray_meets(float ox, float oy, float oz, float ux, float uy, float uz, float o_l1,
-                                          const float4 &q) {
+                                          const float4 &q, float t_limit = 3.0e38f) {
     const float vx = q.x - ox, vy = q.y - oy, vz = q.z - oz;
     const float along = vx * ux + vy * uy + vz * uz;
     const float wx = vx - along * ux, wy = vy - along * uy, wz = vz - along * uz; // centre minus its foot on the line
     const float dist2 = wx * wx + wy * wy + wz * wz;
     const float len = fabsf(vx) + fabsf(vy) + fabsf(vz);
     const float reach = q.w + 3.8146973e-06f * (len + o_l1 + fabsf(q.x) + fabsf(q.y) + fabsf(q.z) + 1.0f); // 2^-18
-    return dist2 <= reach * reach * 1.00001f && along >= -reach;
+    return dist2 <= reach * reach * 1.00001f && along >= -reach && along - reach <= t_limit;
 }
 // For a triangle the bounding sphere is followed by its plane: Triangle::CalcIntersect misses when the normal
 // does not face the ray (anyobject.h:487-492), and where the ray meets the plane must lie inside the bounding
@@ -1294,42 +1301,126 @@ __device__ __forceinline__ bool ray_meets_plane_of(float ox, float oy, float oz,
     const float reach = q.w + slack;
     return px * px + py * py + pz * pz <= reach * reach;
 }
-// The same search ray by ray: a lane walks the table's tree on its own (super -> chunks -> groups of 8 ->
-// primitives), one sphere test per turn of ONE loop, the position in the tree kept as (level, index) and moved
-// by index arithmetic -- down to the first child after a sphere the ray may hit, else on to the next sibling,
-// up when the siblings end.  For waves whose rays fan out (mirror rays off small spheres) the shared beam
-// holds most of the scene and the walk per ray is the cheaper one.
-__device__ __forceinline__ void walk_ray(const GeneralTable &t, float ox, float oy, float oz, float ux, float uy, float uz,
-                                         float o_l1, uint32_t rid, uint32_t n_rays, uint32_t *__restrict__ cand,
-                                         uint32_t &cnt, const Spill &sp, uint32_t &n_pairs) {
-    // levels: 0 super, 1 chunk (64 per super), 2 group of 8 (8 per chunk), 3 primitive (8 per group)
+// The same search ray by ray: a lane walks an 8-ary tree over the same order of primitives on its own.  Level L
+// of `nodes` holds the bounding BOXES of runs of 8^(n_lvls - 1 - L) primitives (a flat patch of triangles fills
+// its box and very little of its sphere, and a ray that skims the patch would enter every sphere on its way);
+// the boxes of the last level are those of the primitives.  A turn of the loop loads the 8 children of one node
+// -- 64 bytes, the boxes as bytes on a grid of the node's own: lanes that walk apart each fetch their own lines,
+// and the fetch is what a turn costs -- tests them all, and keeps the answers as a byte of a mask per level.  For waves whose rays fan out (mirror rays off small spheres, gather rays) the shared
+// beam holds most of the scene and the walk per ray is the cheaper one.
+__device__ __forceinline__ uint32_t level_offset(int lvl) { return ((8u << (3 * lvl)) - 8u) / 7u; } // nodes above level lvl
+// A ray prepared for the box tests: the origin moved out by the ray's share of the margin on either side (the
+// boxes carry their own share), and the reciprocal of the direction.
+struct BoxRay { float opx, opy, opz, omx, omy, omz, ix, iy, iz; };
+__device__ __forceinline__ float recip_clamped(float u) { return 1.0f / (fabsf(u) < 1e-20f ? (u < 0.0f ? -1e-20f : 1e-20f) : u); }
+__device__ __forceinline__ BoxRay box_ray(float ox, float oy, float oz, float ux, float uy, float uz, float o_l1) {
+    const float e = 3.8146973e-06f * o_l1 * 1.0001f; // 2^-18
+    BoxRay r;
+    r.opx = ox + e; r.opy = oy + e; r.opz = oz + e;
+    r.omx = ox - e; r.omy = oy - e; r.omz = oz - e;
+    r.ix = recip_clamped(ux); r.iy = recip_clamped(uy); r.iz = recip_clamped(uz);
+    return r;
+}
+// The 8 children of one node, 64 bytes: the group's low corner (3 floats), a word of three power-of-two
+// exponents and a mask of the children that exist, then the children's boxes as bytes on the grid
+// corner + q * 2^(exponent - 127): lo.x[8], lo.y[8], lo.z[8], hi.x[8], hi.y[8], hi.z[8] (lo rounded down, hi up).
+// Slab test: the ray is inside a box between the latest entry and the earliest exit over the three axes; a box
+// wholly behind the origin, or entered later than t_limit, is passed over.  The margins (box_ray, and
+// build_general_table for the boxes) are 2^-18 of the coordinates involved on each side, 32 times the rounding
+// of the ray to fp32 and of this arithmetic.
+__device__ __forceinline__ float byte_of(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
+__device__ __forceinline__ uint32_t meets8_box(const uint4 *__restrict__ g, const BoxRay &r, float t_limit) {
+    const uint4 h = g[0], qa = g[1], qb = g[2], qc = g[3];
+    const float gx = __uint_as_float(h.x), gy = __uint_as_float(h.y), gz = __uint_as_float(h.z);
+    const float kx = __uint_as_float((h.w & 0xffu) << 23) * r.ix, ky = __uint_as_float(((h.w >> 8) & 0xffu) << 23) * r.iy,
+                kz = __uint_as_float(((h.w >> 16) & 0xffu) << 23) * r.iz;
+    const float x0 = (gx - r.opx) * r.ix, x1 = (gx - r.omx) * r.ix;
+    const float y0 = (gy - r.opy) * r.iy, y1 = (gy - r.omy) * r.iy;
+    const float z0 = (gz - r.opz) * r.iz, z1 = (gz - r.omz) * r.iz;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = j & 3;
+        const float ax = fmaf(byte_of(j < 4 ? qa.x : qa.y, k), kx, x0), bx = fmaf(byte_of(j < 4 ? qb.z : qb.w, k), kx, x1);
+        const float ay = fmaf(byte_of(j < 4 ? qa.z : qa.w, k), ky, y0), by = fmaf(byte_of(j < 4 ? qc.x : qc.y, k), ky, y1);
+        const float az = fmaf(byte_of(j < 4 ? qb.x : qb.y, k), kz, z0), bz = fmaf(byte_of(j < 4 ? qc.z : qc.w, k), kz, z1);
+        const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        m |= (t_in <= t_out * 1.000001f && t_out >= 0.0f && t_in <= t_limit) ? (1u << j) : 0u;
+    }
+    return m & (h.w >> 24);
+}
+// The walk only has to deliver the candidates the CLOSEST hit is among: as soon as one candidate is known to be
+// hit at t > 0 -- by the reference's own formula, evaluated here in fp64 on a plane before the walk and on every
+// sphere or triangle as it becomes a candidate -- nothing the ray enters later than that can be the closest, and
+// boxes and spheres beyond are passed over.  (A mesh that a triangle hit at exactly t = 0 removes could void such
+// a bound; closest_hit<.., PRUNED> sends that ray to the walk over everything.)
+__device__ __forceinline__ void walk_ray(const GeneralTable &t, const SceneView &s, const Ray &e, float ox, float oy, float oz,
+                                         float ux, float uy, float uz, float o_l1, uint32_t rid, uint32_t n_rays,
+                                         uint32_t *__restrict__ cand, uint32_t &cnt, const Spill &sp, uint32_t &n_pairs) {
+    if (t.n_lvls <= 0) return;
+    const int last = t.n_lvls - 1;
+    const BoxRay br = box_ray(ox, oy, oz, ux, uy, uz, o_l1);
+    double t_hit = RT_FLT_MAX;
+    for (int p = 0; p < t.n_planes; p++) {
+        const DObject &o = s.objects[s.prim_obj[t.plane_id[p] & CAND_INDEX]];
+        if (o.type != RT_OBJ_PLANE) continue;
+        const double tp = plane_t(o, e);
+        if (tp > 0 && tp < t_hit) t_hit = tp;
+    }
+    float t_limit = t_hit < 1e38 ? __double2float_ru(t_hit) * 1.000001f : 3.0e38f;
     int lvl = 0;
-    uint32_t idx = 0;
-    while (idx < (uint32_t)t.n_supers || lvl > 0) {
-        const float4 q = lvl == 0 ? t.super[idx] : (lvl == 1 ? t.chunk[idx] : (lvl == 2 ? t.mini[idx] : t.prim[idx]));
-        const bool meets = ray_meets(ox, oy, oz, ux, uy, uz, o_l1, q); // NaN padding: no
-        n_pairs++;
-        if (meets && lvl < 3) { // down to the first child
-            idx = idx << (lvl == 0 ? 6 : 3);
-            lvl++;
+    uint32_t base = 0u;            // first of the 8 siblings being visited at level lvl
+    unsigned long long left = 0ull; // byte L: the siblings at level L still to visit
+    uint32_t m = meets8_box(t.nodes, br, t_limit);
+    n_pairs += 8u;
+    while (true) {
+        if (m == 0u) { // this group is done: back to what is left of the parent's
+            if (lvl == 0) break;
+            lvl--;
+            base = (base >> 3) & ~7u;
+            m = (uint32_t)(left >> (8 * lvl)) & 0xffu;
             continue;
         }
-        if (meets && ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, q, t.prim_n[idx]))
-            append_id(t.prim_id[idx], rid, n_rays, cand, cnt, sp);
-        idx++; // next sibling; past the last one, up to the parent's next sibling
-        while (lvl > 0 && (idx & (lvl == 1 ? 63u : 7u)) == 0) {
-            idx >>= (lvl == 1 ? 6 : 3);
-            lvl--;
+        const uint32_t node = base + (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        if (lvl == last) {
+            const float4 q = t.prim[node];
+            if (ray_meets(ox, oy, oz, ux, uy, uz, o_l1, q, t_limit) && // (again: the limit may have come down since)
+                ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, q, t.prim_n[node])) {
+                const uint32_t id = t.prim_id[node];
+                append_id(id, rid, n_rays, cand, cnt, sp);
+                const double4 rec = s.prim_rec[id & CAND_INDEX];
+                double tc = -1;
+                if (id & CAND_SPHERE) {
+                    tc = sphere_t_rec(rec, e);
+                } else if (id & CAND_TRI) {
+                    int outside; d3 ph; double u, v;
+                    tc = tri_t(s.tris[__double2hiint(rec.x)], e, &outside, &ph, &u, &v);
+                }
+                if (tc > 0 && tc < t_hit) {
+                    t_hit = tc;
+                    t_limit = tc < 1e38 ? __double2float_ru(tc) * 1.000001f : 3.0e38f;
+                }
+            }
+            continue;
         }
+        left = (left & ~(0xffull << (8 * lvl))) | ((unsigned long long)m << (8 * lvl));
+        lvl++;
+        base = node * 8u;
+        m = meets8_box(t.nodes + (size_t)(level_offset(lvl) + base) / 8 * 4, br, t_limit);
+        n_pairs += 8u;
     }
 }
 
-__global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const double *__restrict__ ray_d,
+__global__ __launch_bounds__(256) void k_search_general(GeneralTable t, SceneView s, const double *__restrict__ ray_d,
                                                         const uint32_t *__restrict__ list,
                                                         const uint32_t *__restrict__ n_listed, uint32_t n_rays,
                                                         uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_cnt,
-                                                        Spill sp, unsigned long long *__restrict__ counters) {
-    // the rays of this level, compacted in tile order (k_scatter_active): 64 neighbours on screen per wave
+                                                        Spill sp, unsigned long long *__restrict__ counters,
+                                                        float theta_limit) {
+    // the rays of this level, compacted in tile order (k_scatter_active): 64 neighbours on screen per wave.
+    // theta_limit > 0 replaces the table's own limit on the cone a wave may search as one beam.
     const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const size_t n = n_rays;
@@ -1337,9 +1428,13 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
     const uint32_t rid = active ? list[at] : 0u;
     float ox = 0, oy = 0, oz = 0, ux = 0, uy = 0, uz = 0;
     bool odd = false; // a ray the beam cannot hold (no direction, not finite): left to the fp64 walk
+    Ray e;
+    e.pe = D3(0, 0, 0); e.npe = D3(0, 0, 0);
     if (active) {
-        ox = (float)ray_d[0 * n + rid]; oy = (float)ray_d[1 * n + rid]; oz = (float)ray_d[2 * n + rid];
-        ux = (float)ray_d[3 * n + rid]; uy = (float)ray_d[4 * n + rid]; uz = (float)ray_d[5 * n + rid];
+        e.pe = D3(ray_d[0 * n + rid], ray_d[1 * n + rid], ray_d[2 * n + rid]);
+        e.npe = D3(ray_d[3 * n + rid], ray_d[4 * n + rid], ray_d[5 * n + rid]);
+        ox = (float)e.pe.x; oy = (float)e.pe.y; oz = (float)e.pe.z;
+        ux = (float)e.npe.x; uy = (float)e.npe.y; uz = (float)e.npe.z;
         const float ul = ux * ux + uy * uy + uz * uz, ol = fabsf(ox) + fabsf(oy) + fabsf(oz);
         odd = !(ul > 0.99f && ul < 1.01f) || !(ol < t.far_origin);
     }
@@ -1366,8 +1461,8 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
         const float o_l1 = fabsf(ox) + fabsf(oy) + fabsf(oz);
         if (in_beam)
             for (int p = 0; p < t.n_planes; p++) append_id(t.plane_id[p], rid, n_rays, cand, cnt, sp);
-        const bool tight = b.rho <= t.tight_rho && b.theta <= t.tight_theta; // uniform
-        if (!tight && in_beam) walk_ray(t, ox, oy, oz, ux, uy, uz, o_l1, rid, n_rays, cand, cnt, sp, n_pairs);
+        const bool tight = b.rho <= t.tight_rho && b.theta <= (theta_limit > 0.0f ? theta_limit : t.tight_theta); // uniform
+        if (!tight && in_beam) walk_ray(t, s, e, ox, oy, oz, ux, uy, uz, o_l1, rid, n_rays, cand, cnt, sp, n_pairs);
         for (int s0 = 0; tight && s0 < t.n_supers; s0 += 64) {
             const bool meets_s = (s0 + lane < t.n_supers) && beam_meets(b, t.super[s0 + lane]);
             unsigned long long ms = __ballot(meets_s);
@@ -1414,7 +1509,9 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, const do
 // the candidates are walked once more without it; two such meshes send the ray to the ordered walk over
 // everything (as does a ray whose candidates did not fit its own slots AND the bundle's spill list).
 // POSITIVE: the gather loops' rule, an object's hit counts only with t > 0 (shader.h:130,176).
-template <bool POSITIVE = false, bool ENV = true>
+// PRUNED: the candidates come from walk_ray, which stops at the closest hit it knows of: should a mesh be removed,
+// what lies beyond was never listed, and the ray goes to the ordered walk over everything.
+template <bool POSITIVE = false, bool ENV = true, bool PRUNED = false>
 __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                             uint32_t n_rays, const uint32_t *__restrict__ cand,
                                             const uint32_t *__restrict__ cand_cnt, const Spill &sp, Closest &c,
@@ -1484,6 +1581,7 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
                     i = entry.y;
                 }
             c.t_best = bt; c.prim_best = bprim;
+            if (PRUNED && zero_obj >= 0) { two_zero = true; break; }
             if (pass == 0 && zero_obj >= 0 && bobj == zero_obj && !two_zero) exclude = zero_obj; // once more without it
             else break;
         }
@@ -2017,9 +2115,9 @@ __device__ __forceinline__ void closest_hit_walk(const SceneView &s, const Gener
     }
     uint32_t cnt = 0;
     for (int p = 0; p < t.n_planes; p++) append_id(t.plane_id[p], rid, w.n, w.cand, cnt, w.spill);
-    walk_ray(t, ox, oy, oz, ux, uy, uz, o_l1, rid, w.n, w.cand, cnt, w.spill, n_pairs);
+    walk_ray(t, s, e, ox, oy, oz, ux, uy, uz, o_l1, rid, w.n, w.cand, cnt, w.spill, n_pairs);
     w.cand_cnt[rid] = cnt;
-    closest_hit<false, ENV>(s, e, false, rid, w.n, w.cand, w.cand_cnt, w.spill, c, evaluated, overflowed);
+    closest_hit<false, ENV, true>(s, e, false, rid, w.n, w.cand, w.cand_cnt, w.spill, c, evaluated, overflowed);
 }
 // (three waves per SIMD: at the two the compiler picks by itself the frame takes 30 % longer, at four the spills cost more)
 // WALK: a scene of many primitives -- every ray of the pixel's tree, shadow rays included, finds its candidates
@@ -2173,7 +2271,10 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
 // against every object, taking hits with t > 0 only.  cm0 is the object's own colour as CalcIntersect
 // returns it: no texture lookup, lights, border or reflection on this path.  The angles come from
 // rt355x_rotation in place of rand(), their sine and cosine from sincos_rounded.
-struct Gather { const double *dirs; int32_t n; };
+struct Gather {
+    const double *dirs; int32_t n;
+    int32_t grid, per_cell, left_words; // the passes of a searched scene: grid x grid direction cells, per_cell places in each
+};
 // FEW > 0: the scene has at most FEW planes, at most FEW spheres and no mesh (the reference's own scene is
 // two planes and two spheres).  All gather rays of a hit share their origin, so the terms of
 // Plane::CalcIntersect and Sphere::CalcIntersect that depend on the origin alone -- ni . (pe - pi), pe - c,
@@ -2336,14 +2437,40 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
 }
 
 // ---- the gather shaders on searched scenes ----------------------------------------------------------------
-// The camera rays' hits are found as usual (k_resolve_primary writes the hit records), then the direction
-// set is taken ONE direction per pass: k_gather_emit turns it by each hit's two angles and keeps the hits it
-// passes the normal test for, the live rays are compacted and searched in the scene table (k_search_general),
-// k_gather_resolve takes their closest hit with t > 0 on the candidates and adds to the hit's counts and colour
-// sums, and after the last direction k_gather_finish blends the pixel.  The per-hit state lives in the arrays
-// the levels of mirror rays use: lvl_ks[0..3] = sin and cos of the two angles, lvl_clr[0] = cnt,
-// lvl_clr[1..3] = the colour sums.
-__global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w) {
+// The camera rays' hits are found as usual (k_resolve_primary writes the hit records).  Every hit turns the
+// direction set by two angles of its own, so "direction i of every hit" is a set of rays that point anywhere:
+// a wave of them has nothing in common and its lanes walk the scene table apart.  The rays are therefore taken
+// in passes BY WHERE THEY POINT: k_gather_init turns all directions of a hit, keeps those that pass the normal
+// test, and files each under the cell of a grid x grid octahedral map of the sphere it points into -- per_cell
+// places per cell, and a bit in g_left for a direction whose cell was full.  Pass (cell, place) sends, from every
+// hit, the direction filed there (k_gather_emit, which appends the hits that have one to the pass's ray list);
+// pass "left i" sends direction i from the hits that could not place it.  Neighbours on screen then send
+// neighbouring rays, the lanes of a wave walk the same part of the table (k_search_general), and
+// k_gather_resolve takes the closest hit with t > 0 on the candidates and adds to the hit's counts and colour
+// sums: integer sums, so the order of the passes does not matter.  After the last pass k_gather_finish blends
+// the pixel.  The per-hit state lives in the arrays the levels of mirror rays use: lvl_ks[0..3] = sin and cos of
+// the two angles, lvl_clr[0] = cnt, lvl_clr[1..3] = the colour sums.
+#define GATHER_GRID_MAX 16
+__device__ __forceinline__ d3 gather_ray(const Gather &ga, int i, double s1, double c1, double s2, double c2) {
+    const double gx = ga.dirs[3 * i], gy = ga.dirs[3 * i + 1], gz = ga.dirs[3 * i + 2];
+    const double x1 = c1 * gx - s1 * gy, y1 = s1 * gx + c1 * gy;                          // shader.h:115,160
+    return D3(x1, c2 * y1 - s2 * gz, s2 * y1 + c2 * gz);                                  // :119,164
+}
+// the cell of the octahedral map a direction points into (any rule would do: it only orders the work)
+__device__ __forceinline__ int gather_cell(const d3 &r, int grid) {
+    const float x = (float)r.x, y = (float)r.y, z = (float)r.z;
+    const float l1 = fabsf(x) + fabsf(y) + fabsf(z);
+    if (!(l1 > 0.0f) || !(l1 < 1e30f)) return 0;
+    float u = x / l1, v = y / l1;
+    if (z < 0.0f) {
+        const float fu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), fv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f);
+        u = fu; v = fv;
+    }
+    const int cu = min(grid - 1, max(0, (int)((u * 0.5f + 0.5f) * (float)grid)));
+    const int cv = min(grid - 1, max(0, (int)((v * 0.5f + 0.5f) * (float)grid)));
+    return cv * grid + cu;
+}
+__global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w, Gather ga) {
     const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
     if (rid >= f.n_rays || w.rec_obj[rid] < 0) return;
     int x, y;
@@ -2361,29 +2488,82 @@ __global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w) {
     const size_t n = f.n_rays;
     w.lvl_ks[0 * n + rid] = s1; w.lvl_ks[1 * n + rid] = c1; w.lvl_ks[2 * n + rid] = s2; w.lvl_ks[3 * n + rid] = c2;
     w.lvl_clr[0 * n + rid] = 0u; w.lvl_clr[1 * n + rid] = 0u; w.lvl_clr[2 * n + rid] = 0u; w.lvl_clr[3 * n + rid] = 0u;
-}
-__global__ __launch_bounds__(256) void k_gather_emit(Frame f, Work w, Gather ga, int i) {
-    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_gather = 0;
-    float4 rec = nan4();
-    if (rid < f.n_rays && w.rec_obj[rid] >= 0) {
-        const size_t n = f.n_rays;
-        const double s1 = w.lvl_ks[0 * n + rid], c1 = w.lvl_ks[1 * n + rid], s2 = w.lvl_ks[2 * n + rid], c2 = w.lvl_ks[3 * n + rid];
-        const double gx = ga.dirs[3 * i], gy = ga.dirs[3 * i + 1], gz = ga.dirs[3 * i + 2];
-        const double x1 = c1 * gx - s1 * gy, y1 = s1 * gx + c1 * gy;                      // shader.h:115,160
-        const d3 ray = D3(x1, c2 * y1 - s2 * gz, s2 * y1 + c2 * gz);                      // :119,164
-        const d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+    // file the directions (g_slot was filled with 0xffff, g_left with zeros)
+    const d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+    unsigned char filled[GATHER_GRID_MAX * GATHER_GRID_MAX];
+    for (int c = 0; c < ga.grid * ga.grid; c++) filled[c] = 0;
+    unsigned long long left = 0ull;
+    for (int i = 0; i < ga.n; i++) {
+        const d3 ray = gather_ray(ga, i, s1, c1, s2, c2);
         if (!(dot(ray, nh) <= 0)) {                                                       // :122,167
+            const int c = gather_cell(ray, ga.grid);
+            const int place = filled[c];
+            if (place < ga.per_cell) {
+                w.g_slot[(size_t)(c * ga.per_cell + place) * n + rid] = (uint16_t)i;
+                filled[c] = (unsigned char)(place + 1);
+            } else {
+                left |= 1ull << (i & 63);
+            }
+        }
+        if ((i & 63) == 63 || i == ga.n - 1) {
+            if (left) w.g_left[(size_t)(i >> 6) * n + rid] = left;
+            left = 0ull;
+        }
+    }
+}
+// One pass: pass < cells * per_cell sends what is filed at that place, later passes the left-over direction
+// (pass - cells * per_cell).  The hits that send a ray are appended to `list`, neighbours next to each other; a
+// workgroup takes GATHER_EMIT_RUNS runs of 256 hits and claims its part of the list with ONE atomic (all
+// workgroups add to the same counter).
+#define GATHER_EMIT_RUNS 8
+__global__ __launch_bounds__(256) void k_gather_emit(Frame f, Work w, Gather ga, int pass, uint32_t *__restrict__ list) {
+    __shared__ uint32_t wave_sends[GATHER_EMIT_RUNS * 4 + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w.spill.count = 0u; // the pass before this one has been resolved
+    const size_t n = f.n_rays;
+    const int n_placed = ga.grid * ga.grid * ga.per_cell;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int send[GATHER_EMIT_RUNS];
+    uint32_t n_sent = 0u;
+#pragma unroll
+    for (int k = 0; k < GATHER_EMIT_RUNS; k++) {
+        const uint32_t rid = (blockIdx.x * GATHER_EMIT_RUNS + k) * 256u + threadIdx.x;
+        int i = -1;
+        if (rid < f.n_rays && w.rec_obj[rid] >= 0) {
+            if (pass < n_placed) {
+                const uint32_t filed = w.g_slot[(size_t)pass * n + rid];
+                if (filed != 0xffffu) i = (int)filed;
+            } else {
+                const int d = pass - n_placed;
+                if ((w.g_left[(size_t)(d >> 6) * n + rid] >> (d & 63)) & 1ull) i = d;
+            }
+        }
+        if (i >= 0) {
+            const d3 ray = gather_ray(ga, i, w.lvl_ks[0 * n + rid], w.lvl_ks[1 * n + rid], w.lvl_ks[2 * n + rid], w.lvl_ks[3 * n + rid]);
             const Ray vw = mkview(D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]), ray); // :127,173
             w.ray_d[0 * n + rid] = vw.pe.x; w.ray_d[1 * n + rid] = vw.pe.y; w.ray_d[2 * n + rid] = vw.pe.z;
             w.ray_d[3 * n + rid] = vw.npe.x; w.ray_d[4 * n + rid] = vw.npe.y; w.ray_d[5 * n + rid] = vw.npe.z;
-            rec = make_float4((float)vw.npe.x, (float)vw.npe.y, (float)vw.npe.z, 0.f);
-            if (!(rec.x == rec.x)) rec.x = 0.f; // not a number: still a ray; the search leaves it to the fp64 walk
-            n_gather = 1;
+            n_sent++;
         }
+        send[k] = i;
+        const unsigned long long sending = __ballot(i >= 0);
+        if (lane == 0) wave_sends[k * 4 + wave] = (uint32_t)__popcll(sending);
     }
-    if (rid < f.n_rays) w.ray32[rid] = rec;
-    wave_count(w.counters, 7, n_gather);
+    __syncthreads();
+    if (threadIdx.x == 0) { // counts -> offsets within the workgroup's part, then the part's place in the list
+        uint32_t run = 0u;
+        for (int q = 0; q < GATHER_EMIT_RUNS * 4; q++) { const uint32_t c = wave_sends[q]; wave_sends[q] = run; run += c; }
+        wave_sends[GATHER_EMIT_RUNS * 4] = run ? atomicAdd(&w.g_count[pass], run) : 0u;
+    }
+    __syncthreads();
+    const uint32_t part = wave_sends[GATHER_EMIT_RUNS * 4];
+#pragma unroll
+    for (int k = 0; k < GATHER_EMIT_RUNS; k++) {
+        const unsigned long long sending = __ballot(send[k] >= 0);
+        if (send[k] >= 0)
+            list[part + wave_sends[k * 4 + wave] + (uint32_t)__popcll(sending & ((1ull << lane) - 1ull))] =
+                (blockIdx.x * GATHER_EMIT_RUNS + k) * 256u + threadIdx.x;
+    }
+    wave_count(w.counters, 7, n_sent);
 }
 template <bool BLEED>
 __global__ __launch_bounds__(256) void k_gather_resolve(SceneView s, Frame f, Work w, const uint32_t *__restrict__ list,
@@ -2397,7 +2577,7 @@ __global__ __launch_bounds__(256) void k_gather_resolve(SceneView s, Frame f, Wo
         vw.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
         vw.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
         Closest c;
-        closest_hit<true>(s, vw, false, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
+        closest_hit<true, true, true>(s, vw, false, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
         if (BLEED) {
             if (c.t_best < 100) {                                                         // shader.h:181-184
                 const uint32_t hc = s.objects[s.prim_obj[c.prim_best]].rgb;
@@ -2466,7 +2646,10 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         e = grid_ray(cam, f, x, y);
     }
     Closest c;
-    closest_hit<false, ENV>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
+    if (LEVELS && f.level > 0) // mirror rays: their candidates come from walk_ray
+        closest_hit<false, ENV, true>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
+    else
+        closest_hit<false, ENV>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
         w.rec_obj[rid] = -1;
         if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u);
@@ -2786,6 +2969,7 @@ struct rt355_scene {
     int work_slots = 0, table_slots = 0;
     DLight *d_lights = nullptr; int lights_cap = 0;
     double *d_dirs = nullptr; int n_dirs = 0; // direction set of the gather shaders
+    size_t g_slot_rows = 0, g_left_rows = 0, g_count_n = 0; // capacity of Work::g_slot, g_left (rows of work_rays), g_count
     GeneralTable general{};                     // scene table for mirror rays (reflective scenes that are searched)
     bool has_general = false;
     double ks_abs_max = 0;                      // largest |ks| of the scene
@@ -2895,7 +3079,7 @@ inline uint64_t spread21(uint64_t v) { // 21 bits -> every third bit
     v = (v | v << 2) & 0x1249249249249249ull;
     return v;
 }
-struct BoundSphere { double c[3]; double r; uint32_t id; double nrm[3]; bool tri; };
+struct BoundSphere { double c[3]; double r; uint32_t id; double nrm[3]; bool tri; double lo[3], hi[3]; };
 // smallest-effort enclosing sphere of a run of spheres: centre = mean of their centres
 inline BoundSphere enclose(const BoundSphere *b, size_t count) {
     BoundSphere o{};
@@ -2928,12 +3112,17 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
                 double dx = v[0] - b.c[0], dy = v[1] - b.c[1], dz = v[2] - b.c[2];
                 b.r = std::max(b.r, sqrt(dx * dx + dy * dy + dz * dz) * (1 + 1e-12));
             }
+            for (int a = 0; a < 3; a++) {
+                b.lo[a] = std::min(t.p0[a], std::min(t.p1[a], t.p2[a]));
+                b.hi[a] = std::max(t.p0[a], std::max(t.p1[a], t.p2[a]));
+            }
             b.id = (uint32_t)p | CAND_TRI;
             b.tri = true;
             for (int a = 0; a < 3; a++) b.nrm[a] = t.normal[a];
         } else if (o.type == RT_OBJ_SPHERE) {
             for (int a = 0; a < 3; a++) b.c[a] = o.p[a];
             b.r = fabs(o.radius);
+            for (int a = 0; a < 3; a++) { b.lo[a] = b.c[a] - b.r; b.hi[a] = b.c[a] + b.r; }
             b.id = (uint32_t)p | CAND_SPHERE;
         } else { // planes, and environments (a sphere around everything would only bloat its group): candidates of every ray
             planes.push_back((uint32_t)p | (o.type == RT_OBJ_ENVIRONMENT ? CAND_ENVIRONMENT : 0u));
@@ -3004,14 +3193,65 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
         chunk_rows[j] = to_row(chunks[j]);
     }
     for (size_t k = 0; k < n_supers; k++) super_rows[k] = to_row(enclose(&chunks[k * 64], std::min<size_t>(64, n_chunks - k * 64)));
+    // the 8-ary tree of walk_ray: every level's boxes straight from the primitives of the run, moved out by
+    // 2^-18 of (the largest coordinate sum of the box + 1), then put on the byte grid of their group
+    int n_lvls = sorted.empty() ? 0 : 1;
+    for (size_t span = 8; span < sorted.size(); span *= 8) n_lvls++;
+    const size_t last_at = n_lvls ? ((size_t(8) << (3 * (n_lvls - 1))) - 8) / 7 : 0; // nodes above the last level
+    const size_t n_groups_q = std::max<size_t>(1, last_at / 8 + (sorted.size() + 7) / 8);
+    std::vector<uint32_t> nodes(n_groups_q * 16, 0u);
+    for (int L = 0; L < n_lvls; L++) {
+        const size_t span = size_t(1) << (3 * (n_lvls - 1 - L)), at = ((size_t(8) << (3 * L)) - 8) / 7;
+        const size_t n_children = (sorted.size() + span - 1) / span;
+        for (size_t gi = 0; gi * 8 < n_children; gi++) {
+            double blo[8][3], bhi[8][3], glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
+            uint32_t valid = 0u;
+            for (size_t c = 0; c < 8 && gi * 8 + c < n_children; c++) {
+                const size_t i = gi * 8 + c;
+                double lo3[3] = {1e300, 1e300, 1e300}, hi3[3] = {-1e300, -1e300, -1e300};
+                for (size_t q = i * span; q < std::min(sorted.size(), (i + 1) * span); q++)
+                    for (int a = 0; a < 3; a++) { lo3[a] = std::min(lo3[a], sorted[q].lo[a]); hi3[a] = std::max(hi3[a], sorted[q].hi[a]); }
+                double l1 = 1.0;
+                for (int a = 0; a < 3; a++) l1 += std::max(fabs(lo3[a]), fabs(hi3[a]));
+                const double margin = l1 * (1.0 / 262144.0);
+                for (int a = 0; a < 3; a++) {
+                    blo[c][a] = lo3[a] - margin; bhi[c][a] = hi3[a] + margin;
+                    glo[a] = std::min(glo[a], blo[c][a]); ghi[a] = std::max(ghi[a], bhi[c][a]);
+                }
+                valid |= 1u << c;
+            }
+            uint32_t *grp = &nodes[(at / 8 + gi) * 16];
+            uint32_t expo[3];
+            for (int a = 0; a < 3; a++) {
+                const float corner = -round_up(-glo[a]);
+                int e = 0;
+                (void)frexp((ghi[a] - (double)corner) / 254.0, &e); // 2^e >= its argument
+                e = std::min(254, std::max(1, e + 127));
+                while (e < 254 && ldexp(1.0, e - 127) * 254.0 < ghi[a] - (double)corner) e++;
+                const double step = ldexp(1.0, e - 127);
+                memcpy(&grp[a], &corner, sizeof corner);
+                expo[a] = (uint32_t)e;
+                for (size_t c = 0; c < 8; c++) {
+                    if (!((valid >> c) & 1u)) continue;
+                    const uint32_t qlo = (uint32_t)std::min(255.0, std::max(0.0, floor((blo[c][a] - (double)corner) / step)));
+                    const uint32_t qhi = (uint32_t)std::min(255.0, std::max(0.0, ceil((bhi[c][a] - (double)corner) / step)));
+                    grp[4 + a * 2 + c / 4] |= qlo << (8 * (c % 4));
+                    grp[10 + a * 2 + c / 4] |= qhi << (8 * (c % 4));
+                }
+            }
+            grp[3] = expo[0] | (expo[1] << 8) | (expo[2] << 16) | (valid << 24);
+        }
+    }
     GeneralTable &g = sc->general;
     int rc;
-    if ((rc = upload(sc, prim_rows, &g.prim)) || (rc = upload(sc, prim_ids, &g.prim_id)) || (rc = upload(sc, prim_nrm, &g.prim_n)) ||
+    const uint32_t *d_nodes = nullptr;
+    if ((rc = upload(sc, nodes, &d_nodes)) || (rc = upload(sc, prim_rows, &g.prim)) || (rc = upload(sc, prim_ids, &g.prim_id)) || (rc = upload(sc, prim_nrm, &g.prim_n)) ||
         (rc = upload(sc, chunk_rows, &g.chunk)) ||
         (rc = upload(sc, mini_rows, &g.mini)) ||
         (rc = upload(sc, super_rows, &g.super)) || (rc = upload(sc, planes, &g.plane_id)))
         return rc;
-    g.n_supers = (int32_t)n_supers; g.n_planes = (int32_t)planes.size();
+    g.nodes = (const uint4 *)d_nodes;
+    g.n_supers = (int32_t)n_supers; g.n_planes = (int32_t)planes.size(); g.n_lvls = n_lvls;
     double mean_group = 0; // mean radius of the groups of 8: the scale below which a beam is "thin"
     size_t n_groups8 = 0;
     for (size_t m = 0; m * 8 < sorted.size(); m++, n_groups8++) mean_group += mini_rows[m].w;
@@ -3208,8 +3448,10 @@ static void free_tables(rt355_scene *sc) {
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
-                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d};
+                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d,
+                  w.g_slot, w.g_left, w.g_count};
     for (void *p : ps) if (p) (void)hipFree(p);
+    sc->g_slot_rows = sc->g_left_rows = sc->g_count_n = 0;
     unsigned long long *keep = w.counters;
     w = Work{};
     w.counters = keep;
@@ -3369,6 +3611,35 @@ static int ensure_levels(rt355_scene *sc) {
         return RT355_OK;
     drop();
     return fail(RT355_ERR_DEVICE, std::string("level arrays: ") + hipGetErrorString(e));
+}
+
+// The pass arrays of the gather shaders on a searched scene, grown to what the direction set asks for.
+static int ensure_gather(rt355_scene *sc, size_t slot_rows, size_t left_rows, size_t n_count) {
+    Work &wk = sc->work;
+    const size_t cap = sc->work_rays;
+    hipError_t e = hipSuccess;
+    if (slot_rows > sc->g_slot_rows) {
+        if (wk.g_slot) (void)hipFree(wk.g_slot);
+        wk.g_slot = nullptr; sc->g_slot_rows = 0;
+        if ((e = hipMalloc((void **)&wk.g_slot, slot_rows * cap * sizeof(uint16_t))) != hipSuccess)
+            return fail(RT355_ERR_DEVICE, std::string("gather passes: ") + hipGetErrorString(e));
+        sc->g_slot_rows = slot_rows;
+    }
+    if (left_rows > sc->g_left_rows) {
+        if (wk.g_left) (void)hipFree(wk.g_left);
+        wk.g_left = nullptr; sc->g_left_rows = 0;
+        if ((e = hipMalloc((void **)&wk.g_left, left_rows * cap * sizeof(unsigned long long))) != hipSuccess)
+            return fail(RT355_ERR_DEVICE, std::string("gather passes: ") + hipGetErrorString(e));
+        sc->g_left_rows = left_rows;
+    }
+    if (n_count > sc->g_count_n) {
+        if (wk.g_count) (void)hipFree(wk.g_count);
+        wk.g_count = nullptr; sc->g_count_n = 0;
+        if ((e = hipMalloc((void **)&wk.g_count, n_count * sizeof(uint32_t))) != hipSuccess)
+            return fail(RT355_ERR_DEVICE, std::string("gather passes: ") + hipGetErrorString(e));
+        sc->g_count_n = n_count;
+    }
+    return RT355_OK;
 }
 
 // A frame that one kernel renders can be enqueued as several calls, one per group of rows, that count into the
@@ -3723,8 +3994,8 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, one);
             hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, one);
             hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
-            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, w.ray_d, w.active_rid,
-                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
+            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
+                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters, 0.0f);
             HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
             sc->launch_choice.push_back({-1, 0});
             launches++;
@@ -3787,24 +4058,35 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
                            bundles[0].kind ? 0 : 1, none, pix);
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
         resolves = 1;
-        hipLaunchKernelGGL(k_gather_init, dim3(per_ray_blocks), dim3(256), 0, st, f, w);
-        const Gather ga{sc->d_dirs, sc->n_dirs};
+        // the passes: grid x grid direction cells with per_cell places each, then one per direction for what was left
+        Gather ga{sc->d_dirs, sc->n_dirs, 0, 0, 0};
+        ga.grid = std::min(GATHER_GRID_MAX, std::max(2, (int)lround(sqrt(0.85 * (double)sc->n_dirs))));
+        ga.per_cell = 2;
+        float theta_limit = 1e-30f; // never as one beam: the rays of a pass share a cell of directions, not a thin cone
+        if (const char *e = getenv("RT355_GATHER_PASSES")) { // experiments: "grid,per_cell,theta_limit"
+            int g = 0, pc = 0; double th = 0;
+            if (sscanf(e, "%d,%d,%lf", &g, &pc, &th) == 3 && g >= 1 && g <= GATHER_GRID_MAX && pc >= 0 && pc <= 64) {
+                ga.grid = g; ga.per_cell = pc; theta_limit = (float)th;
+            }
+        }
+        ga.left_words = (sc->n_dirs + 63) / 64;
+        const int n_placed = ga.grid * ga.grid * ga.per_cell, n_passes = n_placed + sc->n_dirs;
+        if ((rc = ensure_gather(sc, (size_t)n_placed, (size_t)ga.left_words, (size_t)n_passes))) return rc; // (w refers to sc->work)
+        if (n_placed) HIP_TRY(hipMemsetAsync(w.g_slot, 0xff, (size_t)n_placed * f.n_rays * sizeof(uint16_t), st));
+        if (ga.left_words) HIP_TRY(hipMemsetAsync(w.g_left, 0, (size_t)ga.left_words * f.n_rays * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(w.g_count, 0, (size_t)n_passes * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_gather_init, dim3(per_ray_blocks), dim3(256), 0, st, f, w, ga);
         const bool bleed = opts->shading == RT355_SHADING_BLEED;
-        Slots one{};
-        one.count = 1;
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
-        for (int i = 0; i < sc->n_dirs; i++) {
-            hipLaunchKernelGGL(k_gather_emit, dim3(per_ray_blocks), dim3(256), 0, st, f, w, ga, i);
-            hipLaunchKernelGGL(k_count_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, one);
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, one);
-            hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
-            HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, w.ray_d, w.active_rid,
-                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
+        for (int pass = 0; pass < n_passes; pass++) {
+            hipLaunchKernelGGL(k_gather_emit, dim3((per_ray_blocks + GATHER_EMIT_RUNS - 1) / GATHER_EMIT_RUNS), dim3(256), 0, st, f, w, ga, pass, w.active_rid);
+            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
+                               w.g_count + pass, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters,
+                               theta_limit);
             if (bleed)
-                hipLaunchKernelGGL(k_gather_resolve<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.tile_count + n_tiles);
+                hipLaunchKernelGGL(k_gather_resolve<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.g_count + pass);
             else
-                hipLaunchKernelGGL(k_gather_resolve<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.tile_count + n_tiles);
+                hipLaunchKernelGGL(k_gather_resolve<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.g_count + pass);
         }
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st)); // all passes as one entry of the search times
         sc->launch_choice.push_back({-1, 0});

@@ -28,11 +28,13 @@ for name in sys.argv[1:]:
     search = primary = shade = 0.0
     for _ in range(n):
         r.render_device(cam, sh, o, fb.data_ptr(), 0)
-        r.sync()
+        stats = r.sync()
         search += r.search_kernel_ms()[0]
         per = r.resolve_launch_ms()
         primary += per[0]
         shade += sum(per[1:])
     dt = (time.perf_counter() - t0) / n * 1e3
     print(f"{name:32s} frame {dt:7.3f} ms   search {search / n:6.3f}  primary/direct {primary / n:6.3f}  shade {shade / n:6.3f}", flush=True)
+    if os.environ.get("FRAME_STATS"):
+        print("   ", {k: v for k, v in stats.items() if k != "ms_device"}, flush=True)
     r.close()
