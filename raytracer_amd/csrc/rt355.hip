@@ -182,9 +182,7 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *deepest;    // deepest level the chain of this sub-sample reached
     double *ray_d;        // [6] the ray of the level being traced: pe.xyz, npe.xyz
     // the gather shaders on searched scenes (allocated when such a frame is rendered), see k_gather_init
-    uint16_t *g_slot;           // [cells * per_cell][n] the direction a hit sends in this pass, 0xffff = none
-    unsigned long long *g_left; // [ceil(dirs / 64)][n] the directions of a hit that found no place in its cell
-    uint32_t *g_count;          // [cells * per_cell + dirs] rays of each pass
+    unsigned long long *g_live; // [ceil(dirs / 64)][n] bit i: the hit sends a ray in direction i
 };
 
 // Kernels that work on the rays of several lights at once take the workspace slot from blockIdx.y
@@ -1375,6 +1373,9 @@ __device__ __forceinline__ void walk_ray(const GeneralTable &t, const SceneView 
     uint32_t m = meets8_box(t.nodes, br, t_limit);
     n_pairs += 8u;
     while (true) {
+#ifdef WALK_STATS
+        n_pairs += 1000000u; // turns of the loop, in the millions digit and above
+#endif
         if (m == 0u) { // this group is done: back to what is left of the parent's
             if (lvl == 0) break;
             lvl--;
@@ -1417,10 +1418,8 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, SceneVie
                                                         const uint32_t *__restrict__ list,
                                                         const uint32_t *__restrict__ n_listed, uint32_t n_rays,
                                                         uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_cnt,
-                                                        Spill sp, unsigned long long *__restrict__ counters,
-                                                        float theta_limit) {
-    // the rays of this level, compacted in tile order (k_scatter_active): 64 neighbours on screen per wave.
-    // theta_limit > 0 replaces the table's own limit on the cone a wave may search as one beam.
+                                                        Spill sp, unsigned long long *__restrict__ counters) {
+    // the rays of this level, compacted in tile order (k_scatter_active): 64 neighbours on screen per wave
     const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const size_t n = n_rays;
@@ -1461,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, SceneVie
         const float o_l1 = fabsf(ox) + fabsf(oy) + fabsf(oz);
         if (in_beam)
             for (int p = 0; p < t.n_planes; p++) append_id(t.plane_id[p], rid, n_rays, cand, cnt, sp);
-        const bool tight = b.rho <= t.tight_rho && b.theta <= (theta_limit > 0.0f ? theta_limit : t.tight_theta); // uniform
+        const bool tight = b.rho <= t.tight_rho && b.theta <= t.tight_theta; // uniform
         if (!tight && in_beam) walk_ray(t, s, e, ox, oy, oz, ux, uy, uz, o_l1, rid, n_rays, cand, cnt, sp, n_pairs);
         for (int s0 = 0; tight && s0 < t.n_supers; s0 += 64) {
             const bool meets_s = (s0 + lane < t.n_supers) && beam_meets(b, t.super[s0 + lane]);
@@ -1495,6 +1494,13 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, SceneVie
         }
     }
     if (active) cand_cnt[rid] = odd ? CAND_UNSEARCHED : cnt;
+#ifdef WALK_STATS
+    { // counter 5: turns summed over lanes; counter 3: 64 x the wave's longest
+        const uint32_t turns = n_pairs / 1000000u;
+        wave_count(counters, 3, (uint32_t)wave_max_f((float)turns));
+        n_pairs = turns;
+    }
+#endif
     wave_count(counters, 5, n_pairs);
 }
 
@@ -2271,10 +2277,7 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
 // against every object, taking hits with t > 0 only.  cm0 is the object's own colour as CalcIntersect
 // returns it: no texture lookup, lights, border or reflection on this path.  The angles come from
 // rt355x_rotation in place of rand(), their sine and cosine from sincos_rounded.
-struct Gather {
-    const double *dirs; int32_t n;
-    int32_t grid, per_cell, left_words; // the passes of a searched scene: grid x grid direction cells, per_cell places in each
-};
+struct Gather { const double *dirs; int32_t n; };
 // FEW > 0: the scene has at most FEW planes, at most FEW spheres and no mesh (the reference's own scene is
 // two planes and two spheres).  All gather rays of a hit share their origin, so the terms of
 // Plane::CalcIntersect and Sphere::CalcIntersect that depend on the origin alone -- ni . (pe - pi), pe - c,
@@ -2437,42 +2440,25 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
 }
 
 // ---- the gather shaders on searched scenes ----------------------------------------------------------------
-// The camera rays' hits are found as usual (k_resolve_primary writes the hit records).  Every hit turns the
-// direction set by two angles of its own, so "direction i of every hit" is a set of rays that point anywhere:
-// a wave of them has nothing in common and its lanes walk the scene table apart.  The rays are therefore taken
-// in passes BY WHERE THEY POINT: k_gather_init turns all directions of a hit, keeps those that pass the normal
-// test, and files each under the cell of a grid x grid octahedral map of the sphere it points into -- per_cell
-// places per cell, and a bit in g_left for a direction whose cell was full.  Pass (cell, place) sends, from every
-// hit, the direction filed there (k_gather_emit, which appends the hits that have one to the pass's ray list);
-// pass "left i" sends direction i from the hits that could not place it.  Neighbours on screen then send
-// neighbouring rays, the lanes of a wave walk the same part of the table (k_search_general), and
-// k_gather_resolve takes the closest hit with t > 0 on the candidates and adds to the hit's counts and colour
-// sums: integer sums, so the order of the passes does not matter.  After the last pass k_gather_finish blends
-// the pixel.  The per-hit state lives in the arrays the levels of mirror rays use: lvl_ks[0..3] = sin and cos of
-// the two angles, lvl_clr[0] = cnt, lvl_clr[1..3] = the colour sums.
-#define GATHER_GRID_MAX 16
+// The camera rays' hits are found as usual (k_resolve_primary writes the hit records).  k_gather_init gives
+// every hit its two angles and marks the directions of the set that, turned by them, pass the normal test;
+// k_gather_walk sends those rays through the scene table and adds what they hit to the hit's counts and colour
+// sums; k_gather_finish blends the pixel.  The per-hit state lives in the arrays the levels of mirror rays use:
+// lvl_ks[0..3] = sin and cos of the two angles, lvl_clr[0] = cnt, lvl_clr[1..3] = the colour sums.
 __device__ __forceinline__ d3 gather_ray(const Gather &ga, int i, double s1, double c1, double s2, double c2) {
     const double gx = ga.dirs[3 * i], gy = ga.dirs[3 * i + 1], gz = ga.dirs[3 * i + 2];
     const double x1 = c1 * gx - s1 * gy, y1 = s1 * gx + c1 * gy;                          // shader.h:115,160
     return D3(x1, c2 * y1 - s2 * gz, s2 * y1 + c2 * gz);                                  // :119,164
 }
-// the cell of the octahedral map a direction points into (any rule would do: it only orders the work)
-__device__ __forceinline__ int gather_cell(const d3 &r, int grid) {
-    const float x = (float)r.x, y = (float)r.y, z = (float)r.z;
-    const float l1 = fabsf(x) + fabsf(y) + fabsf(z);
-    if (!(l1 > 0.0f) || !(l1 < 1e30f)) return 0;
-    float u = x / l1, v = y / l1;
-    if (z < 0.0f) {
-        const float fu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), fv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f);
-        u = fu; v = fv;
-    }
-    const int cu = min(grid - 1, max(0, (int)((u * 0.5f + 0.5f) * (float)grid)));
-    const int cv = min(grid - 1, max(0, (int)((v * 0.5f + 0.5f) * (float)grid)));
-    return cv * grid + cu;
-}
 __global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w, Gather ga) {
     const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rid >= f.n_rays || w.rec_obj[rid] < 0) return;
+    if (rid >= f.n_rays) return;
+    const size_t n = f.n_rays;
+    const int words = (ga.n + 63) / 64;
+    if (w.rec_obj[rid] < 0) {
+        for (int k = 0; k < words; k++) w.g_live[(size_t)k * n + rid] = 0ull;
+        return;
+    }
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
     int px = x, py = frame_row(f, y), sample = 0; // the sub-sample this hit belongs to keys the two random numbers
@@ -2485,111 +2471,183 @@ __global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w, Gather ga)
     double s1, c1, s2, c2;
     sincos_rounded(theta1, &s1, &c1);
     sincos_rounded(theta2, &s2, &c2);
-    const size_t n = f.n_rays;
     w.lvl_ks[0 * n + rid] = s1; w.lvl_ks[1 * n + rid] = c1; w.lvl_ks[2 * n + rid] = s2; w.lvl_ks[3 * n + rid] = c2;
     w.lvl_clr[0 * n + rid] = 0u; w.lvl_clr[1 * n + rid] = 0u; w.lvl_clr[2 * n + rid] = 0u; w.lvl_clr[3 * n + rid] = 0u;
-    // file the directions (g_slot was filled with 0xffff, g_left with zeros)
     const d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
-    unsigned char filled[GATHER_GRID_MAX * GATHER_GRID_MAX];
-    for (int c = 0; c < ga.grid * ga.grid; c++) filled[c] = 0;
-    unsigned long long left = 0ull;
+    unsigned long long live = 0ull;
     for (int i = 0; i < ga.n; i++) {
-        const d3 ray = gather_ray(ga, i, s1, c1, s2, c2);
-        if (!(dot(ray, nh) <= 0)) {                                                       // :122,167
-            const int c = gather_cell(ray, ga.grid);
-            const int place = filled[c];
-            if (place < ga.per_cell) {
-                w.g_slot[(size_t)(c * ga.per_cell + place) * n + rid] = (uint16_t)i;
-                filled[c] = (unsigned char)(place + 1);
-            } else {
-                left |= 1ull << (i & 63);
-            }
-        }
+        if (!(dot(gather_ray(ga, i, s1, c1, s2, c2), nh) <= 0)) live |= 1ull << (i & 63);  // :122,167
         if ((i & 63) == 63 || i == ga.n - 1) {
-            if (left) w.g_left[(size_t)(i >> 6) * n + rid] = left;
-            left = 0ull;
+            w.g_live[(size_t)(i >> 6) * n + rid] = live;
+            live = 0ull;
         }
     }
 }
-// One pass: pass < cells * per_cell sends what is filed at that place, later passes the left-over direction
-// (pass - cells * per_cell).  The hits that send a ray are appended to `list`, neighbours next to each other; a
-// workgroup takes GATHER_EMIT_RUNS runs of 256 hits and claims its part of the list with ONE atomic (all
-// workgroups add to the same counter).
-#define GATHER_EMIT_RUNS 8
-__global__ __launch_bounds__(256) void k_gather_emit(Frame f, Work w, Gather ga, int pass, uint32_t *__restrict__ list) {
-    __shared__ uint32_t wave_sends[GATHER_EMIT_RUNS * 4 + 1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *w.spill.count = 0u; // the pass before this one has been resolved
-    const size_t n = f.n_rays;
-    const int n_placed = ga.grid * ga.grid * ga.per_cell;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int send[GATHER_EMIT_RUNS];
-    uint32_t n_sent = 0u;
-#pragma unroll
-    for (int k = 0; k < GATHER_EMIT_RUNS; k++) {
-        const uint32_t rid = (blockIdx.x * GATHER_EMIT_RUNS + k) * 256u + threadIdx.x;
-        int i = -1;
-        if (rid < f.n_rays && w.rec_obj[rid] >= 0) {
-            if (pass < n_placed) {
-                const uint32_t filed = w.g_slot[(size_t)pass * n + rid];
-                if (filed != 0xffffu) i = (int)filed;
-            } else {
-                const int d = pass - n_placed;
-                if ((w.g_left[(size_t)(d >> 6) * n + rid] >> (d & 63)) & 1ull) i = d;
-            }
-        }
-        if (i >= 0) {
-            const d3 ray = gather_ray(ga, i, w.lvl_ks[0 * n + rid], w.lvl_ks[1 * n + rid], w.lvl_ks[2 * n + rid], w.lvl_ks[3 * n + rid]);
-            const Ray vw = mkview(D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]), ray); // :127,173
-            w.ray_d[0 * n + rid] = vw.pe.x; w.ray_d[1 * n + rid] = vw.pe.y; w.ray_d[2 * n + rid] = vw.pe.z;
-            w.ray_d[3 * n + rid] = vw.npe.x; w.ray_d[4 * n + rid] = vw.npe.y; w.ray_d[5 * n + rid] = vw.npe.z;
-            n_sent++;
-        }
-        send[k] = i;
-        const unsigned long long sending = __ballot(i >= 0);
-        if (lane == 0) wave_sends[k * 4 + wave] = (uint32_t)__popcll(sending);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { // counts -> offsets within the workgroup's part, then the part's place in the list
-        uint32_t run = 0u;
-        for (int q = 0; q < GATHER_EMIT_RUNS * 4; q++) { const uint32_t c = wave_sends[q]; wave_sends[q] = run; run += c; }
-        wave_sends[GATHER_EMIT_RUNS * 4] = run ? atomicAdd(&w.g_count[pass], run) : 0u;
-    }
-    __syncthreads();
-    const uint32_t part = wave_sends[GATHER_EMIT_RUNS * 4];
-#pragma unroll
-    for (int k = 0; k < GATHER_EMIT_RUNS; k++) {
-        const unsigned long long sending = __ballot(send[k] >= 0);
-        if (send[k] >= 0)
-            list[part + wave_sends[k * 4 + wave] + (uint32_t)__popcll(sending & ((1ull << lane) - 1ull))] =
-                (blockIdx.x * GATHER_EMIT_RUNS + k) * 256u + threadIdx.x;
-    }
-    wave_count(w.counters, 7, n_sent);
-}
+// All rays in one launch, by waves that stay.  The (direction, hit) pairs are taken 64 consecutive hits of one
+// direction at a time, chunk k by wave k mod (number of waves); a lane that is free looks at the next pair, and if
+// the hit sends a ray in that direction builds the ray and walks the scene table with it (walk_ray's loop, one
+// turn at a time), keeping the closest hit by the fp64 formulas as it goes instead of listing candidates.  Rays of
+// one wave end their walks at very different times (a third of the lanes' turns would be used if every wave took
+// 64 rays and waited for the last, and a launch per direction would wait for the longest walk of each), so free
+// lanes are handed new pairs whenever WALK_REFILL of them are free.  A finished ray adds to its hit's counts with
+// atomics: integer sums, in any order.  (Taking the rays by the part of the sphere they point into, so that the
+// lanes of a wave walk the same part of the table, was measured and gained nothing: the walk is bound by
+// instruction issue, not by its loads.)
+// The closest hit is the smallest (t, primitive) over t > 0, as closest_hit<POSITIVE> has it; a triangle hit at
+// exactly t = 0 (its mesh is removed, and the walk may have passed over what lies behind) sends the ray to the
+// walk over everything.  !BLEED only asks whether there is a hit (shader.h:130-133): after the first one only
+// what the ray's origin lies in is still looked at, for such a triangle.
+#ifndef WALK_REFILL
+#define WALK_REFILL 16
+#endif
+#ifndef WALK_TURNS
+#define WALK_TURNS 2
+#endif
+#ifndef WALK_WAVES
+#define WALK_WAVES 4 // waves per SIMD (128 registers): at 3 the frame takes a quarter longer, at 5 the spills cost more
+#endif
 template <bool BLEED>
-__global__ __launch_bounds__(256) void k_gather_resolve(SceneView s, Frame f, Work w, const uint32_t *__restrict__ list,
-                                                        const uint32_t *__restrict__ n_listed) {
-    const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_eval = 0, n_over = 0;
-    if (at < *n_listed) {
-        const uint32_t rid = list[at];
-        const size_t n = f.n_rays;
-        Ray vw;
-        vw.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
-        vw.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
-        Closest c;
-        closest_hit<true, true, true>(s, vw, false, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
+__global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t, SceneView s, Frame f, Work w, Gather ga) {
+    const int lane = threadIdx.x & 63;
+    const size_t n = f.n_rays;
+    const int last = t.n_lvls - 1;
+    const uint32_t per_pass = (f.n_rays + 63u) / 64u, n_chunks = (uint32_t)ga.n * per_pass, n_waves = gridDim.x * 4u;
+    // the wave's place in the pairs (uniform)
+    uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t taken = 0u; // pairs of the chunk already looked at
+    // a lane's ray and where its walk stands
+    bool has = false;
+    uint32_t rid = 0u, base = 0u, m = 0u, n_pairs = 0u, n_exact = 0u, n_sent = 0u;
+    int lvl = 0, bprim = -1;
+    bool zero_tri = false;
+    unsigned long long left = 0ull;
+    Ray e;
+    e.pe = D3(0, 0, 0); e.npe = D3(0, 0, 0);
+    float ox = 0, oy = 0, oz = 0, ux = 0, uy = 0, uz = 0, o_l1 = 0, t_limit = 0;
+    double bt = RT_FLT_MAX;
+    BoxRay br = box_ray(0, 0, 0, 1, 0, 0, 0);
+    auto consider = [&](double tc, int prim) {
+        if (tc > 0 && (tc < bt || (tc == bt && prim < bprim))) {
+            bt = tc; bprim = prim;
+            t_limit = BLEED ? (tc < 1e38 ? __double2float_ru(tc) * 1.000001f : 3.0e38f) : 0.0f;
+        }
+    };
+    auto finish = [&]() { // the ray's closest hit is known (or must be asked of everything): add it to the hit's sums
+        if (zero_tri) {
+            closest_by_kind<true, !BLEED>(s, e, bt, bprim);
+            n_exact += (uint32_t)s.n_prims;
+        }
         if (BLEED) {
-            if (c.t_best < 100) {                                                         // shader.h:181-184
-                const uint32_t hc = s.objects[s.prim_obj[c.prim_best]].rgb;
-                w.lvl_clr[1 * n + rid] += cr(hc); w.lvl_clr[2 * n + rid] += cg(hc); w.lvl_clr[3 * n + rid] += cb(hc);
-                w.lvl_clr[0 * n + rid] += 2u;
+            if (bt < 100) {                                                               // shader.h:181-184
+                const uint32_t hc = s.objects[s.prim_obj[bprim]].rgb;
+                atomicAdd(&w.lvl_clr[1 * n + rid], cr(hc)); atomicAdd(&w.lvl_clr[2 * n + rid], cg(hc)); atomicAdd(&w.lvl_clr[3 * n + rid], cb(hc));
+                atomicAdd(&w.lvl_clr[0 * n + rid], 2u);
             }
-        } else if (c.prim_best >= 0) {                                                    // :130-133
-            w.lvl_clr[0 * n + rid] += 2u;
+        } else if (bprim >= 0) {                                                          // :130-133
+            atomicAdd(&w.lvl_clr[0 * n + rid], 2u);
+        }
+        has = false;
+    };
+    while (true) {
+        unsigned long long idle = __ballot(!has);
+        while (chunk < n_chunks && (uint32_t)__popcll(idle) >= WALK_REFILL) { // uniform
+            const uint32_t pass = chunk / per_pass, first = (chunk - pass * per_pass) * 64u;
+            const uint32_t mine = taken + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!has && mine < 64u && first + mine < f.n_rays) {
+                const uint32_t r = first + mine;
+                const int i = (int)pass;
+                if ((w.g_live[(size_t)(pass >> 6) * n + r] >> (pass & 63u)) & 1ull) {
+                    rid = r;
+                    n_sent++;
+                    const d3 ray = gather_ray(ga, i, w.lvl_ks[0 * n + rid], w.lvl_ks[1 * n + rid], w.lvl_ks[2 * n + rid], w.lvl_ks[3 * n + rid]);
+                    e = mkview(D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]), ray); // shader.h:127,173
+                    ox = (float)e.pe.x; oy = (float)e.pe.y; oz = (float)e.pe.z;
+                    ux = (float)e.npe.x; uy = (float)e.npe.y; uz = (float)e.npe.z;
+                    const float ul = ux * ux + uy * uy + uz * uz;
+                    o_l1 = fabsf(ox) + fabsf(oy) + fabsf(oz);
+                    bt = RT_FLT_MAX; bprim = -1; t_limit = 3.0e38f;
+                    has = true;
+                    if (!(ul > 0.99f && ul < 1.01f) || !(o_l1 < t.far_origin)) {
+                        zero_tri = true; // a ray the table cannot answer for: everything is asked
+                        finish();
+                    } else {
+                        zero_tri = false;
+                        for (int p = 0; p < t.n_planes; p++) { // planes, environments, quadrics: candidates of every ray
+                            const uint32_t id = t.plane_id[p];
+                            const int prim = (int)(id & CAND_INDEX);
+                            const double4 rec = s.prim_rec[prim];
+                            double tc;
+                            if ((id & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
+                                int inside;
+                                tc = environment_t_rec(rec, e, &inside);
+                            } else if (__double2hiint(rec.x) == REC_QUADRIC) {
+                                int outside, branch;
+                                tc = quadric_t(s.quadrics[s.objects[__double2loint(rec.x)].tri_begin], e, &outside, &branch);
+                            } else {
+                                tc = plane_t(s.objects[__double2loint(rec.x)], e);
+                            }
+                            consider(tc, prim);
+                        }
+                        n_exact += (uint32_t)t.n_planes;
+                        if (last < 0) {
+                            finish();
+                        } else {
+                            br = box_ray(ox, oy, oz, ux, uy, uz, o_l1);
+                            lvl = 0; base = 0u; left = 0ull;
+                            m = meets8_box(t.nodes, br, t_limit);
+                            n_pairs += 8u;
+                        }
+                    }
+                }
+            }
+            taken += (uint32_t)__popcll(idle);
+            if (taken >= 64u) { chunk += n_waves; taken = 0u; }
+            idle = __ballot(!has);
+        }
+        if (idle == ~0ull) { // uniform: no lane has a ray
+            if (chunk >= n_chunks) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int turn = 0; turn < WALK_TURNS; turn++) {
+            if (!has) continue;
+            if (m == 0u) { // this group is done: back to what is left of the parent's
+                if (lvl == 0) { finish(); continue; }
+                lvl--;
+                base = (base >> 3) & ~7u;
+                m = (uint32_t)(left >> (8 * lvl)) & 0xffu;
+                continue;
+            }
+            const uint32_t node = base + (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            if (lvl == last) {
+                const float4 q = t.prim[node];
+                if (ray_meets(ox, oy, oz, ux, uy, uz, o_l1, q, t_limit) && // (again: the limit may have come down since)
+                    ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, q, t.prim_n[node])) {
+                    const uint32_t id = t.prim_id[node];
+                    const double4 rec = s.prim_rec[id & CAND_INDEX];
+                    n_exact++;
+                    if (id & CAND_TRI) {
+                        int outside; d3 ph; double u, v;
+                        const double tc = tri_t(s.tris[__double2hiint(rec.x)], e, &outside, &ph, &u, &v);
+                        if (tc == 0) zero_tri = true; // also -0.0
+                        consider(tc, (int)(id & CAND_INDEX));
+                    } else {
+                        consider(sphere_t_rec(rec, e), (int)(id & CAND_INDEX));
+                    }
+                }
+                continue;
+            }
+            left = (left & ~(0xffull << (8 * lvl))) | ((unsigned long long)m << (8 * lvl));
+            lvl++;
+            base = node * 8u;
+            m = meets8_box(t.nodes + (size_t)(level_offset(lvl) + base) / 8 * 4, br, t_limit);
+            n_pairs += 8u;
         }
     }
-    wave_count(w.counters, 1, n_eval);
-    wave_count(w.counters, 2, n_over);
+    wave_count(w.counters, 5, n_pairs);
+    wave_count(w.counters, 1, n_exact);
+    wave_count(w.counters, 7, n_sent);
 }
 template <bool BLEED>
 __global__ __launch_bounds__(256) void k_gather_finish(SceneView s, ShaderView sh, Frame f, Work w, Gather ga,
@@ -2969,7 +3027,7 @@ struct rt355_scene {
     int work_slots = 0, table_slots = 0;
     DLight *d_lights = nullptr; int lights_cap = 0;
     double *d_dirs = nullptr; int n_dirs = 0; // direction set of the gather shaders
-    size_t g_slot_rows = 0, g_left_rows = 0, g_count_n = 0; // capacity of Work::g_slot, g_left (rows of work_rays), g_count
+    size_t g_live_rows = 0; // capacity of Work::g_live (rows of work_rays)
     GeneralTable general{};                     // scene table for mirror rays (reflective scenes that are searched)
     bool has_general = false;
     double ks_abs_max = 0;                      // largest |ks| of the scene
@@ -3449,9 +3507,9 @@ static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
                   w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d,
-                  w.g_slot, w.g_left, w.g_count};
+                  w.g_live};
     for (void *p : ps) if (p) (void)hipFree(p);
-    sc->g_slot_rows = sc->g_left_rows = sc->g_count_n = 0;
+    sc->g_live_rows = 0;
     unsigned long long *keep = w.counters;
     w = Work{};
     w.counters = keep;
@@ -3613,32 +3671,15 @@ static int ensure_levels(rt355_scene *sc) {
     return fail(RT355_ERR_DEVICE, std::string("level arrays: ") + hipGetErrorString(e));
 }
 
-// The pass arrays of the gather shaders on a searched scene, grown to what the direction set asks for.
-static int ensure_gather(rt355_scene *sc, size_t slot_rows, size_t left_rows, size_t n_count) {
+// The array of the gather shaders on a searched scene, grown to what the direction set asks for.
+static int ensure_gather(rt355_scene *sc, size_t live_rows) {
     Work &wk = sc->work;
-    const size_t cap = sc->work_rays;
-    hipError_t e = hipSuccess;
-    if (slot_rows > sc->g_slot_rows) {
-        if (wk.g_slot) (void)hipFree(wk.g_slot);
-        wk.g_slot = nullptr; sc->g_slot_rows = 0;
-        if ((e = hipMalloc((void **)&wk.g_slot, slot_rows * cap * sizeof(uint16_t))) != hipSuccess)
-            return fail(RT355_ERR_DEVICE, std::string("gather passes: ") + hipGetErrorString(e));
-        sc->g_slot_rows = slot_rows;
-    }
-    if (left_rows > sc->g_left_rows) {
-        if (wk.g_left) (void)hipFree(wk.g_left);
-        wk.g_left = nullptr; sc->g_left_rows = 0;
-        if ((e = hipMalloc((void **)&wk.g_left, left_rows * cap * sizeof(unsigned long long))) != hipSuccess)
-            return fail(RT355_ERR_DEVICE, std::string("gather passes: ") + hipGetErrorString(e));
-        sc->g_left_rows = left_rows;
-    }
-    if (n_count > sc->g_count_n) {
-        if (wk.g_count) (void)hipFree(wk.g_count);
-        wk.g_count = nullptr; sc->g_count_n = 0;
-        if ((e = hipMalloc((void **)&wk.g_count, n_count * sizeof(uint32_t))) != hipSuccess)
-            return fail(RT355_ERR_DEVICE, std::string("gather passes: ") + hipGetErrorString(e));
-        sc->g_count_n = n_count;
-    }
+    if (live_rows <= sc->g_live_rows) return RT355_OK;
+    if (wk.g_live) (void)hipFree(wk.g_live);
+    wk.g_live = nullptr; sc->g_live_rows = 0;
+    const hipError_t e = hipMalloc((void **)&wk.g_live, live_rows * (size_t)sc->work_rays * sizeof(unsigned long long));
+    if (e != hipSuccess) return fail(RT355_ERR_DEVICE, std::string("gather rays: ") + hipGetErrorString(e));
+    sc->g_live_rows = live_rows;
     return RT355_OK;
 }
 
@@ -3995,7 +4036,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, one);
             hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
             hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
-                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters, 0.0f);
+                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
             HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
             sc->launch_choice.push_back({-1, 0});
             launches++;
@@ -4058,36 +4099,15 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
                            bundles[0].kind ? 0 : 1, none, pix);
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
         resolves = 1;
-        // the passes: grid x grid direction cells with per_cell places each, then one per direction for what was left
-        Gather ga{sc->d_dirs, sc->n_dirs, 0, 0, 0};
-        ga.grid = std::min(GATHER_GRID_MAX, std::max(2, (int)lround(sqrt(0.85 * (double)sc->n_dirs))));
-        ga.per_cell = 2;
-        float theta_limit = 1e-30f; // never as one beam: the rays of a pass share a cell of directions, not a thin cone
-        if (const char *e = getenv("RT355_GATHER_PASSES")) { // experiments: "grid,per_cell,theta_limit"
-            int g = 0, pc = 0; double th = 0;
-            if (sscanf(e, "%d,%d,%lf", &g, &pc, &th) == 3 && g >= 1 && g <= GATHER_GRID_MAX && pc >= 0 && pc <= 64) {
-                ga.grid = g; ga.per_cell = pc; theta_limit = (float)th;
-            }
-        }
-        ga.left_words = (sc->n_dirs + 63) / 64;
-        const int n_placed = ga.grid * ga.grid * ga.per_cell, n_passes = n_placed + sc->n_dirs;
-        if ((rc = ensure_gather(sc, (size_t)n_placed, (size_t)ga.left_words, (size_t)n_passes))) return rc; // (w refers to sc->work)
-        if (n_placed) HIP_TRY(hipMemsetAsync(w.g_slot, 0xff, (size_t)n_placed * f.n_rays * sizeof(uint16_t), st));
-        if (ga.left_words) HIP_TRY(hipMemsetAsync(w.g_left, 0, (size_t)ga.left_words * f.n_rays * sizeof(unsigned long long), st));
-        HIP_TRY(hipMemsetAsync(w.g_count, 0, (size_t)n_passes * sizeof(uint32_t), st));
+        const Gather ga{sc->d_dirs, sc->n_dirs};
+        int walk_blocks = 8192; // waves that stay, four to a workgroup: several times what the chip holds at once, so that the last ones even out
+        if (const char *e = getenv("RT355_WALK_BLOCKS")) walk_blocks = std::max(1, atoi(e));
+        if ((rc = ensure_gather(sc, (size_t)(sc->n_dirs + 63) / 64))) return rc; // (w refers to sc->work)
         hipLaunchKernelGGL(k_gather_init, dim3(per_ray_blocks), dim3(256), 0, st, f, w, ga);
         const bool bleed = opts->shading == RT355_SHADING_BLEED;
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
-        for (int pass = 0; pass < n_passes; pass++) {
-            hipLaunchKernelGGL(k_gather_emit, dim3((per_ray_blocks + GATHER_EMIT_RUNS - 1) / GATHER_EMIT_RUNS), dim3(256), 0, st, f, w, ga, pass, w.active_rid);
-            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
-                               w.g_count + pass, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters,
-                               theta_limit);
-            if (bleed)
-                hipLaunchKernelGGL(k_gather_resolve<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.g_count + pass);
-            else
-                hipLaunchKernelGGL(k_gather_resolve<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w, w.active_rid, w.g_count + pass);
-        }
+        if (bleed) hipLaunchKernelGGL(k_gather_walk<true>, dim3((unsigned)walk_blocks), dim3(256), 0, st, sc->general, sc->view, f, w, ga);
+        else hipLaunchKernelGGL(k_gather_walk<false>, dim3((unsigned)walk_blocks), dim3(256), 0, st, sc->general, sc->view, f, w, ga);
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st)); // all passes as one entry of the search times
         sc->launch_choice.push_back({-1, 0});
         launches++;
