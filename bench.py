@@ -459,9 +459,11 @@ def measure(name, args, ctx):
         # a frame rendered level by level: the launches of all levels are summed in kernel_time (search includes
         # k_search_general, resolve_primary is level 0's, shade the rest); the per-kernel byte models below describe
         # one level and are not applied
-        out["roofline"] = {"bound": "hbm", "kernel": "levels", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": None, "traffic": None,
-                           "note": "multi-level frame: see profiles/ for the per-kernel trace"}
+        out["roofline"] = {"bound": "hbm", "kernel": "k_gather_walk" if stats["gather_rays"] > 0 else "levels", "achieved": None,
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                           "note": ("one launch walks the scene table for every gather ray; bound by instruction issue, not by HBM: "
+                                    "see profiles/ for its trace and counters" if stats["gather_rays"] > 0 else
+                                    "multi-level frame: see profiles/ for the per-kernel trace")}
     elif not searched:
         # k_render_direct: the reference's own algorithm (every primitive tested for the camera ray and for every
         # shadow ray, fp64), one thread per pixel.  Priced as the reference-formula flops of those tests against
@@ -521,8 +523,8 @@ def measure(name, args, ctx):
         if stride == 0:
             work = scene.n_primitives * (1 + len(shader.lights))
             stride = 1 if work < 200 else (4 if work < 5000 else (16 if work < 1_000_000 else 64))
-        if shading:
-            stride = 4
+        if shading:  # a gather shader tests every primitive for every direction of every hit
+            stride = 4 if scene.n_primitives * len(dirs) < 5000 else 64
         out["cpu_baseline"] = cpu_baseline(scene, shader, dev_cams[-1], w, h, stride, threads, shading, dirs, gpu_frame)
     r.close()
     host.close()
@@ -531,7 +533,7 @@ def measure(name, args, ctx):
 
 HEADLINE = "default_4k"
 OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "mesh100k_sweep60", "default_bleed162_4k",
-          "spheres10k_mirrors_8lights_4k", "glass_room_4k", "spheres10k_glass_8lights_4k"]
+          "spheres10k_mirrors_8lights_4k", "glass_room_4k", "spheres10k_glass_8lights_4k", "mesh100k_bleed42_4k"]
 
 
 def spawn_ranks(n: int) -> int:

@@ -695,6 +695,55 @@ def test_glass_among_many_spheres(api, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_spheres", [0, 1, 7, 8, 9, 63, 64, 65, 511, 513])
+def test_scene_table_of_every_depth(api, oracle, n_spheres):
+    """The scene table the mirror, glass and gather rays walk is an 8-ary tree over the spheres and triangles:
+    scenes whose tree is absent (planes only), one group, and just below / at / above a power of 8, padded with
+    planes to the 64 primitives from which a scene is searched.  Mirrors, glass and both gather shaders against
+    the checker."""
+    rng = S.SplitMix64(4242 + n_spheres)
+    sc = S.Scene()
+    sc.add_plane((0, 0, -12), (0, 0, 1), (1, 0, 0), (200, 200, 210), ks=0.4)
+    sc.add_plane((0, 60, 0), (0, -1, 0), (1, 0, 0), (210, 180, 160))
+    for k in range(max(0, 64 - n_spheres - 2)):   # more planes, all behind the camera
+        sc.add_plane((0, -200 - k, 0), (0, 1, 0), (1, 0, 0), (90, 90, 90))
+    for i in range(n_spheres):
+        c = (rng.uniform(-22, 22), rng.uniform(18, 50), rng.uniform(-10, 14))
+        sc.add_sphere(c, rng.uniform(0.8, 3.0) if n_spheres > 20 else rng.uniform(2.5, 6.0),
+                      (int(rng.uniform(40, 255)), int(rng.uniform(40, 255)), int(rng.uniform(40, 255))),
+                      ks=0.5 if i % 3 == 0 else 0.0)
+    assert sc.n_primitives >= 64
+    sh = S.Shader(S.ring_lights(2), 0x101010, 0xDDDDDD, 0x202020)
+    w, h = 96, 64
+    cam = S.default_camera(w, h)
+    r = api.Renderer(sc)
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    got, st = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
+    _compare(got, want)
+    assert st["secondary_rays"] == wst["secondary_rays"] > 0 and st["shadow_rays"] == wst["shadow_rays"]
+    dirs = B.geodesic(B.icosphere(1))
+    r.set_directions(dirs)
+    for shading in (B.SHADING_BLEED, B.SHADING_OCCLUSION):
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, seed=3, shading=shading), threads=0, dirs=dirs)
+        got, st = r.render(cam, sh, w, h, seed=3, shading=shading, mode=B.MODE_PACKET)
+        _compare(got, want)
+        assert st["gather_rays"] == wst["gather_rays"] > 0
+    r.close()
+    if n_spheres >= 7:   # the same scene with every other sphere of glass, in a closed box
+        for i, o in enumerate(sc.objects):
+            if o["type"] == B.OBJ_SPHERE and i % 2:
+                o["fresnel"] = 0.4
+                o["ior"] = 1.4
+        sc.add_environment((0, 40, 0), 500, (120, 150, 230))
+        r = api.Renderer(sc)
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+        got, st = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
+        _compare(got, want)
+        assert st["secondary_rays"] == wst["secondary_rays"] > 0
+        r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(60, 66))
 def test_random_scenes_with_textures(api, oracle, seed):
     """The random scenes with texture mapping (type 1), solid textures with random projectors (type 2) and the
