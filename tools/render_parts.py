@@ -1,6 +1,6 @@
 """GPU box: ms per frame of rt355_render (page-locked pixmap) with the pixels written straight into the mapped pixmap
-("direct", the default) and with a readback by copy in 1 .. 8 parts (RT355_READBACK_COPY, RT355_RENDER_PARTS), beside
-rt355_render_device ("dev").  Usage: python tools/render_parts.py WORKLOAD..."""
+("direct"), with a readback by copy in 1 .. 8 parts ("4", "6s", "6sd": RT355_READBACK_COPY, RT355_RENDER_PARTS) and
+as the library chooses by itself ("auto"), beside rt355_render_device ("dev").  Usage: python tools/render_parts.py WORKLOAD..."""
 import os
 import sys
 import time
@@ -21,11 +21,18 @@ for name in sys.argv[1:]:
     host = HostPixmap(w, h)
     fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     line = [name]
-    for parts in ("dev", "direct", "1", "2", "4"):
-        os.environ.pop("RT355_READBACK_COPY", None)
-        if parts not in ("dev", "direct"):
+    for parts in os.environ.get("PARTS", "dev auto direct 1 4 6 6sd").split():
+        for k in ("RT355_READBACK_COPY", "RT355_READBACK_DIRECT", "RT355_COPY_STREAMS", "RT355_LAST_COPIED", "RT355_RENDER_PARTS"):
+            os.environ.pop(k, None)
+        if parts == "direct":
+            os.environ["RT355_READBACK_DIRECT"] = "1"
+        elif parts not in ("dev", "auto"):  # "4": four parts, one copy stream, all copied; "6s": two copy streams; "6sd": last part written directly
             os.environ["RT355_READBACK_COPY"] = "1"
-            os.environ["RT355_RENDER_PARTS"] = parts
+            os.environ["RT355_RENDER_PARTS"] = parts.rstrip("sd")
+            if "s" not in parts:
+                os.environ["RT355_COPY_STREAMS"] = "1"
+            if "d" not in parts:
+                os.environ["RT355_LAST_COPIED"] = "1"
         def frame():
             if parts == "dev":
                 r.render_device(cam, sh, B.opts(w, h, shading=shading), fb.data_ptr(), 0)
