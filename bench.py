@@ -489,13 +489,20 @@ def measure(name, args, ctx):
         avg_ms = acc["primary_ms"] / K
         tf = flops / (avg_ms * 1e-3) / 1e12
         refracts = bool((scene.pack().objects["fresnel"] < 1).any()) and not shading
-        out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_gather" if shading else ("k_render_refract" if refracts else "k_render_direct"), "achieved": round(tf, 3),
-                           "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 5),
-                           "traffic": None, "launches_per_frame": 1, "avg_launch_ms": round(avg_ms, 4),
-                           "algorithmic_flops_per_frame": flops, "flops_per_test": ALGO_FLOPS,
-                           "algorithmic_bytes_per_frame": float(3 * w * h),
-                           "note": "arithmetic is fp64 (half the fp32 rate); per-hit shading is not in the flop count"
-                                   + ("; nor are the tests of the mirror and refracted rays" if stats["secondary_rays"] else "")}
+        if refracts and scene.n_primitives >= 64:
+            # every ray of the pixel's tree walks the scene table: the tests are those of the walk, not one per primitive
+            out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_refract", "achieved": None, "peak": PEAK_FP32_TFLOPS,
+                               "unit": "TFLOP/s", "frac": None, "traffic": None, "launches_per_frame": 1, "avg_launch_ms": round(avg_ms, 4),
+                               "box_tests_per_frame": stats["pair_tests"], "candidates_evaluated_fp64": stats["exact_tests"],
+                               "note": "one kernel per frame that walks the scene table for every ray; bound by instruction issue"}
+        else:
+            out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_gather" if shading else ("k_render_refract" if refracts else "k_render_direct"), "achieved": round(tf, 3),
+                               "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 5),
+                               "traffic": None, "launches_per_frame": 1, "avg_launch_ms": round(avg_ms, 4),
+                               "algorithmic_flops_per_frame": flops, "flops_per_test": ALGO_FLOPS,
+                               "algorithmic_bytes_per_frame": float(3 * w * h),
+                               "note": "arithmetic is fp64 (half the fp32 rate); per-hit shading is not in the flop count"
+                                       + ("; nor are the tests of the mirror and refracted rays" if stats["secondary_rays"] else "")}
     else:
         rooflines = {"k_resolve_primary": hbm_roofline("k_resolve_primary", primary_bytes(stats, n_rays_padded, nl, True),
                                                        acc["primary_ms"], K)}

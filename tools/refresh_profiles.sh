@@ -8,7 +8,8 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 for p in "trace_default default_4k" "trace_spheres10k spheres10k_8lights_4k" "trace_mesh100k mesh100k_2lights_4k" \
          "trace_bleed162 default_bleed162_4k" "trace_mirrors10k spheres10k_mirrors_8lights_4k" \
-         "trace_glass glass_room_4k" "trace_default_mirrors default_mirrors_4k" "trace_mesh1m_8k mesh1m_2lights_8k"; do
+         "trace_glass glass_room_4k" "trace_default_mirrors default_mirrors_4k" "trace_mesh1m_8k mesh1m_2lights_8k" \
+         "trace_mesh100k_bleed42 mesh100k_bleed42_4k" "trace_glass10k spheres10k_glass_8lights_4k"; do
   set -- $p
   bash tools/trace_pass.sh ${R}_$1 $2 > /dev/null || exit 1
   echo "done $1" >> gpurun_out/refresh_progress.txt
@@ -21,7 +22,8 @@ bash tools/traffic_passes.sh default_4k spheres10k_8lights_4k mesh100k_2lights_4
 cp gpurun_out/traffic.json gpurun_out/${R}_traffic.json
 echo "done traffic" >> gpurun_out/refresh_progress.txt
 for p in "pmc_spheres10k_sq spheres10k_8lights_4k" "pmc_mesh100k_sq mesh100k_2lights_4k" "pmc_default_sq default_4k" \
-         "pmc_glass_sq glass_room_4k" "pmc_bleed162_sq default_bleed162_4k"; do
+         "pmc_glass_sq glass_room_4k" "pmc_bleed162_sq default_bleed162_4k" "pmc_mesh100k_bleed42_sq mesh100k_bleed42_4k" \
+         "pmc_mirrors10k_sq spheres10k_mirrors_8lights_4k"; do
   set -- $p
   bash tools/pmc_pass.sh ${R}_$1 $2 -- SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES > /dev/null || exit 1
   echo "done $1" >> gpurun_out/refresh_progress.txt

@@ -1,10 +1,13 @@
 #!/bin/bash
 # HBM-side traffic of every kernel of the bench workloads: one FETCH_SIZE pass and one WRITE_SIZE pass each
 # (the two do not fit one pass), merged into gpurun_out/traffic.json by tools/traffic_merge.py.
+# rt355_render is told to render every frame with one launch into the framebuffer in HBM and copy it back, so that
+# every launch of a kernel moves one frame's bytes through HBM (by itself it may write a page-locked pixmap directly).
 # Usage (GPU box): bash tools/traffic_passes.sh <workload> [...]
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
+export RT355_READBACK_COPY=1 RT355_RENDER_PARTS=1
 for wl in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     tag=traffic_${wl}_$c
