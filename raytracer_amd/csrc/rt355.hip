@@ -205,6 +205,26 @@ __device__ __forceinline__ void wave_count(unsigned long long *counters, int whi
         atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + which], (unsigned long long)v);
 }
 
+// The same for a kernel that counts once, at its end, and whose every thread gets there: the waves' sums meet in
+// LDS and one atomic per counter and WORKGROUP goes out.  (A device-wide atomic is a transaction with memory of its
+// own on this chip -- the XCDs' L2s share no lines -- and the counters see it as 32 bytes written: three per wave
+// were half as many bytes again as the pixels of the default frame.)
+template <int N>
+__device__ __forceinline__ void block_count(unsigned long long *counters, const int (&which)[N], const uint32_t (&value)[N]) {
+    __shared__ uint32_t tally[N];
+    if (threadIdx.x < N) tally[threadIdx.x] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        uint32_t v = value[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&tally[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < N && tally[threadIdx.x])
+        atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + which[threadIdx.x]], (unsigned long long)tally[threadIdx.x]);
+}
 
 __device__ __forceinline__ float4 nan4() {
     float q = __builtin_nanf("");
@@ -1753,9 +1773,6 @@ __device__ __forceinline__ void direct_store(unsigned char *__restrict__ pixmap,
         if (valid) w.rec_sum[xy_to_rid(x, y, f.tiles_x)] = clr;
         return;
     }
-    // (the four waves of a workgroup store together: their 768 bytes then leave the L2 as whole lines -- without
-    // the barrier the counters see 1.5 times the frame written)
-    __syncthreads();
     store_row_segment<DIRECT_SEG>(pixmap, f, x, y, valid, clr);
 }
 // CalcPixel's average over the alias x alias sub-samples of a pixel (main.cpp:315-325): sums of the
@@ -2022,11 +2039,7 @@ __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneVie
     pixel = clr;
     } while (0);
     direct_store(pixmap, f, w, x, y, valid, pixel);
-    wave_count(w.counters, 4, n_hit);
-    wave_count(w.counters, 0, n_shadow);
-    wave_count(w.counters, 1, n_eval);
-    wave_count(w.counters, 2, n_over);
-    if (REFLECT) wave_count(w.counters, 6, n_secondary);
+    block_count<5>(w.counters, {4, 0, 1, 2, 6}, {n_hit, n_shadow, n_eval, n_over, REFLECT ? n_secondary : 0u});
 }
 
 // ---- refraction -----------------------------------------------------------------------------------------
@@ -2262,13 +2275,7 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
     pixel = value;
     } while (0);
     direct_store(pixmap, f, w, x, y, valid, pixel);
-    wave_count(w.counters, 4, n_hit);
-    wave_count(w.counters, 0, n_shadow);
-    wave_count(w.counters, 1, n_eval);
-    wave_count(w.counters, 2, n_over);
-    wave_count(w.counters, 6, n_secondary);
-    wave_count(w.counters, 14, n_deep);
-    if (WALK) wave_count(w.counters, 5, n_pairs);
+    block_count<7>(w.counters, {4, 0, 1, 2, 6, 14, 5}, {n_hit, n_shadow, n_eval, n_over, n_secondary, n_deep, WALK ? n_pairs : 0u});
 }
 
 // CalcSubPixel2 (main.cpp:163-209), the renderer HEAD of the reference selects: the closest hit as in
@@ -2435,9 +2442,7 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
     pixel = clr;
     } while (0);
     direct_store(pixmap, f, w, x, y, valid, pixel);
-    wave_count(w.counters, 4, n_hit);
-    wave_count(w.counters, 1, n_eval);
-    wave_count(w.counters, 7, n_gather);
+    block_count<3>(w.counters, {4, 1, 7}, {n_hit, n_eval, n_gather});
 }
 
 // ---- the gather shaders on searched scenes ----------------------------------------------------------------

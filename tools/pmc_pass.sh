@@ -12,4 +12,5 @@ echo "# rocprofv3 --pmc $* -- python3 bench.py --steps 3 --warmup 1 --workload $
 timeout -s KILL 120 rocprofv3 --pmc "$@" -d gpurun_out/$tag -- python3 bench.py --steps 3 --warmup 1 --workload $wl --no-others --no-allpairs --no-cpu-baseline "${extra[@]}" > gpurun_out/$tag.log 2>&1 || { tail -n 5 gpurun_out/$tag.log; exit 1; }
 db=$(find gpurun_out/$tag -name '*.db' | head -n 1)
 python3 tools/prof_summary.py "$db" >> gpurun_out/$tag.txt 2>&1
+[ -n "$KEEP_RAW" ] || rm -rf gpurun_out/$tag gpurun_out/$tag.log
 grep -E "k_shade_group|k_resolve_primary|k_search|k_render|k_gather" gpurun_out/$tag.txt | head -n 40

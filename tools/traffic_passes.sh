@@ -14,6 +14,7 @@ for wl in "$@"; do
     timeout -s KILL 150 rocprofv3 --pmc $c -d gpurun_out/$tag -- python3 bench.py --steps 3 --warmup 1 --workload $wl --no-others --no-allpairs --no-cpu-baseline > gpurun_out/$tag.log 2>&1 || { tail -n 5 gpurun_out/$tag.log; exit 1; }
     db=$(find gpurun_out/$tag -name '*.db' | head -n 1)
     python3 tools/prof_summary.py "$db" > gpurun_out/$tag.txt 2>&1 || exit 1
+    [ -n "$KEEP_RAW" ] || rm -rf gpurun_out/$tag gpurun_out/$tag.log
   done
 done
 python3 tools/traffic_merge.py "$@" > gpurun_out/traffic.json && cat gpurun_out/traffic.json | head -c 1500
