@@ -134,7 +134,10 @@ typedef struct rt355_shader {
 
 /* ---- render options ------------------------------------------------------------------ */
 /* All three modes produce the same frame, byte for byte; they differ in how the ray/primitive
- * pairs that the fp64 reference formulas must evaluate are found. */
+ * pairs that the fp64 reference formulas must evaluate are found.  (The searches bound every primitive by
+ * where the reference's own test can report a hit: a triangle whose inside test is rounding noise -- its
+ * deciding cross-product component, anyobject.h:512-513, vanishing beside the others -- is taken or left by the
+ * reference anywhere on its plane, and is therefore a candidate of every ray, like a plane.) */
 #define RT355_MODE_ALLPAIRS 0 /* fp32 conservative test of EVERY ray/primitive pair (FP32-VALU bound) */
 #define RT355_MODE_BRUTE    1 /* fp64 formulas on every pair, no search (debug / tiny scenes)         */
 #define RT355_MODE_PACKET   2 /* as ALLPAIRS, but a workgroup first culls the primitive table against

@@ -239,6 +239,22 @@ __device__ __forceinline__ uint32_t cand_id(const SceneView &s, int prim) {
     const int type = s.objects[s.prim_obj[prim]].type;
     return (uint32_t)prim | (type == RT_OBJ_SPHERE ? CAND_SPHERE : (type == RT_OBJ_ENVIRONMENT ? CAND_ENVIRONMENT : 0u));
 }
+// Triangle::CalcIntersect takes u and v from ONE component of the cross products, the first of AA = (p1 - p0) x
+// (p2 - p0) that is not zero (anyobject.h:512-513).  Where that component is rounding noise beside the others -- a
+// slanted plane that contains the x direction, say -- u and v are noise too, and the reference accepts or rejects
+// points anywhere on the triangle's plane.  No bound of the triangle then holds its hits: such a triangle is a
+// candidate of every ray, like a plane, in every table.
+__host__ __device__ inline bool triangle_is_unbounded(const double *p0, const double *p1, const double *p2) {
+#ifdef RT355_IGNORE_UNBOUNDED_TRIANGLES // (to see the tests that need this fail)
+    return false;
+#endif
+    const double ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+    const double bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+    const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx; // cross(), rt_exact.h
+    const double sel = (cx != 0) ? cx : ((cy != 0) ? cy : cz);
+    const double big = fmax(fabs(cx), fmax(fabs(cy), fabs(cz)));
+    return fabs(sel) < 1e-6 * big;
+}
 // L1[i] = (ox, oy, oz, -thr): unit axis and negated cosine threshold of a cone, seen from the
 // bundle origin, that contains primitive i.  A ray with unit direction d can only hit i if
 // d . o - thr >= 0.  -thr = +2 marks "always a candidate" (planes, origin inside the sphere),
@@ -274,7 +290,9 @@ __device__ __forceinline__ TableRow bundle_origin_row(const SceneView &s, d3 O, 
                 d3 w = vsub(O, pc);
                 cull = dot(nrm, w) > 1e-9 * (1.0 + vlen(w));
             }
-            if (!cull) {
+            if (!cull && triangle_is_unbounded(t.p0, t.p1, t.p2)) {
+                l1 = always; sin_t = 0.f;
+            } else if (!cull) {
                 ctr = pc;
                 double r0 = vlen(vsub(p0, pc)), r1 = vlen(vsub(p1, pc)), r2 = vlen(vsub(p2, pc));
                 rad = fmax(r0, fmax(r1, r2));
@@ -360,7 +378,9 @@ __device__ __forceinline__ TableRow bundle_direction_row(const SceneView &s, con
         } else {
             const DTriangle &t = s.tris[tri];
             d3 p0 = ld3(t.p0), p1 = ld3(t.p1), p2 = ld3(t.p2), nrm = ld3(t.normal), pc = ld3(t.p_center);
-            if (!(dot(nrm, w) > 1e-12)) { // back-face test of anyobject.h:490 is the same for every ray
+            if (!(dot(nrm, w) > 1e-12) && triangle_is_unbounded(t.p0, t.p1, t.p2)) {
+                l1 = always;
+            } else if (!(dot(nrm, w) > 1e-12)) { // back-face test of anyobject.h:490 is the same for every ray
                 ctr = pc;
                 rad = fmax(vlen(vsub(p0, pc)), fmax(vlen(vsub(p1, pc)), vlen(vsub(p2, pc))));
                 round_like = true;
@@ -2578,7 +2598,7 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
                         finish();
                     } else {
                         zero_tri = false;
-                        for (int p = 0; p < t.n_planes; p++) { // planes, environments, quadrics: candidates of every ray
+                        for (int p = 0; p < t.n_planes; p++) { // planes, environments, quadrics, unbounded triangles: candidates of every ray
                             const uint32_t id = t.plane_id[p];
                             const int prim = (int)(id & CAND_INDEX);
                             const double4 rec = s.prim_rec[prim];
@@ -2586,6 +2606,10 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
                             if ((id & CAND_ENVIRONMENT) == CAND_ENVIRONMENT) {
                                 int inside;
                                 tc = environment_t_rec(rec, e, &inside);
+                            } else if (id & CAND_TRI) { // a triangle no bound holds (triangle_is_unbounded)
+                                int outside; d3 ph; double u, v;
+                                tc = tri_t(s.tris[__double2hiint(rec.x)], e, &outside, &ph, &u, &v);
+                                if (tc == 0) zero_tri = true;
                             } else if (__double2hiint(rec.x) == REC_QUADRIC) {
                                 int outside, branch;
                                 tc = quadric_t(s.quadrics[s.objects[__double2loint(rec.x)].tri_begin], e, &outside, &branch);
@@ -3174,7 +3198,10 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     for (size_t p = 0; p < prim_obj.size(); p++) {
         const DObject &o = objs[prim_obj[p]];
         BoundSphere b{};
-        if (prim_tri[p] >= 0) {
+        if (prim_tri[p] >= 0 && triangle_is_unbounded(tris[prim_tri[p]].p0, tris[prim_tri[p]].p1, tris[prim_tri[p]].p2)) {
+            planes.push_back((uint32_t)p | CAND_TRI); // no bound holds its hits: a candidate of every ray
+            continue;
+        } else if (prim_tri[p] >= 0) {
             const DTriangle &t = tris[prim_tri[p]];
             for (int a = 0; a < 3; a++) b.c[a] = (t.p0[a] + t.p1[a] + t.p2[a]) / 3.0;
             for (const double *v : {t.p0, t.p1, t.p2}) {

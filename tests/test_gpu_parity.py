@@ -695,6 +695,44 @@ def test_glass_among_many_spheres(api, oracle):
 
 
 @pytest.mark.gpu
+def test_triangle_whose_inside_test_is_noise(api, oracle):
+    """Triangle::CalcIntersect takes u and v from the first component of (p1 - p0) x (p2 - p0) that is not zero
+    (anyobject.h:512-513).  These triangles lie in a slanted plane that contains the x direction: that component
+    is 7e-15 beside 310, rounding noise, so u and v are noise and the reference takes or leaves points anywhere on
+    the plane.  The searched modes must give what the walk over everything gives: such a triangle is a candidate of
+    every ray (camera, shadow, mirror, gather)."""
+    p0, p1, p2 = (-27.38, 17.98, -6.56), (17.62, 33.64, -1.34), (-27.38, 24.88, -4.26)
+    tris = np.zeros((2, 15))
+    tris[0, :9] = p0 + p1 + p2
+    tris[1, :9] = p0 + p2 + p1   # the other winding: one of the two faces the camera
+    sc = S.Scene()
+    sc.add_plane((0, 0, -12), (0, 0, 1), (1, 0, 0), (200, 200, 210), ks=0.5)
+    sc.add_mesh(tris, clr=(230, 90, 60))
+    rng = S.SplitMix64(99)
+    for i in range(70):
+        sc.add_sphere((rng.uniform(-25, 25), rng.uniform(10, 45), rng.uniform(-10, 6)), rng.uniform(0.6, 1.8),
+                      (int(rng.uniform(40, 255)), int(rng.uniform(40, 255)), int(rng.uniform(40, 255))))
+    sh = S.Shader(S.ring_lights(2) + [B.light_src(0, (0, 0, 0), (0.2, 0.3, -1.0), (1, 1, 1))], 0x101010, 0xDDDDDD, 0x202020)
+    w, h = 160, 120
+    cam = S.default_camera(w, h)
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+    mesh_pixels = int((np.abs(want.astype(int) - np.array([230, 90, 60])).sum(axis=2) < 200).sum())
+    r = api.Renderer(sc)
+    for mode in (B.MODE_BRUTE, B.MODE_PACKET, B.MODE_ALLPAIRS):
+        got, st = r.render(cam, sh, w, h, mode=mode)
+        _compare(got, want)
+        assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"], mode
+    dirs = B.geodesic(B.icosphere(1))
+    r.set_directions(dirs)
+    want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, seed=5, shading=B.SHADING_BLEED), threads=0, dirs=dirs)
+    got, st = r.render(cam, sh, w, h, seed=5, shading=B.SHADING_BLEED, mode=B.MODE_PACKET)
+    _compare(got, want)
+    assert st["gather_rays"] == wst["gather_rays"] > 0
+    r.close()
+    assert mesh_pixels >= 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_spheres", [0, 1, 7, 8, 9, 63, 64, 65, 511, 513])
 def test_scene_table_of_every_depth(api, oracle, n_spheres):
     """The scene table the mirror, glass and gather rays walk is an 8-ary tree over the spheres and triangles:
