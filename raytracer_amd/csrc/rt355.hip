@@ -243,7 +243,11 @@ __device__ __forceinline__ uint32_t cand_id(const SceneView &s, int prim) {
 // (p2 - p0) that is not zero (anyobject.h:512-513).  Where that component is rounding noise beside the others -- a
 // slanted plane that contains the x direction, say -- u and v are noise too, and the reference accepts or rejects
 // points anywhere on the triangle's plane.  No bound of the triangle then holds its hits: such a triangle is a
-// candidate of every ray, like a plane, in every table.
+// candidate of every ray, like a plane, in every table.  The limit: with coordinates of size P and a triangle of
+// size S the computed u is off by about 8 * 2^-53 * P * S / |component|, so the reference takes points up to that
+// times S outside an edge; at a component of 1e-7 of the largest (|AA| ~ S^2) that is 1e-8 * P, a tenth of what the
+// tightest margin of the searches allows at that size (1e-6 rad in the bundle tables, 2^-18 relative in the scene
+// table), and every such triangle costs every ray an fp64 test -- hence not larger.
 __host__ __device__ inline bool triangle_is_unbounded(const double *p0, const double *p1, const double *p2) {
 #ifdef RT355_IGNORE_UNBOUNDED_TRIANGLES // (to see the tests that need this fail)
     return false;
@@ -253,7 +257,7 @@ __host__ __device__ inline bool triangle_is_unbounded(const double *p0, const do
     const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx; // cross(), rt_exact.h
     const double sel = (cx != 0) ? cx : ((cy != 0) ? cy : cz);
     const double big = fmax(fabs(cx), fmax(fabs(cy), fabs(cz)));
-    return fabs(sel) < 1e-6 * big;
+    return fabs(sel) < 1e-7 * big;
 }
 // L1[i] = (ox, oy, oz, -thr): unit axis and negated cosine threshold of a cone, seen from the
 // bundle origin, that contains primitive i.  A ray with unit direction d can only hit i if
@@ -1373,18 +1377,27 @@ __device__ __forceinline__ uint32_t meets8_box(const uint4 *__restrict__ g, cons
     const float gx = __uint_as_float(h.x), gy = __uint_as_float(h.y), gz = __uint_as_float(h.z);
     const float kx = __uint_as_float((h.w & 0xffu) << 23) * r.ix, ky = __uint_as_float(((h.w >> 8) & 0xffu) << 23) * r.iy,
                 kz = __uint_as_float(((h.w >> 16) & 0xffu) << 23) * r.iz;
-    const float x0 = (gx - r.opx) * r.ix, x1 = (gx - r.omx) * r.ix;
-    const float y0 = (gy - r.opy) * r.iy, y1 = (gy - r.omy) * r.iy;
-    const float z0 = (gz - r.opz) * r.iz, z1 = (gz - r.omz) * r.iz;
+    // along an axis the ray runs up, a box is entered through its lower face and left through its upper one, and
+    // the other way round: which bytes are "in" and which "out" is settled once per node, not per box
+    const bool ux = r.ix >= 0.0f, uy = r.iy >= 0.0f, uz = r.iz >= 0.0f;
+    const uint32_t xi0 = ux ? qa.x : qb.z, xi1 = ux ? qa.y : qb.w, xo0 = ux ? qb.z : qa.x, xo1 = ux ? qb.w : qa.y;
+    const uint32_t yi0 = uy ? qa.z : qc.x, yi1 = uy ? qa.w : qc.y, yo0 = uy ? qc.x : qa.z, yo1 = uy ? qc.y : qa.w;
+    const uint32_t zi0 = uz ? qb.x : qc.z, zi1 = uz ? qb.y : qc.w, zo0 = uz ? qc.z : qb.x, zo1 = uz ? qc.w : qb.y;
+    // (lower faces are taken from the origin moved up by the ray's margin, upper faces from the origin moved down)
+    const float xl = (gx - r.opx) * r.ix, xh = (gx - r.omx) * r.ix;
+    const float yl = (gy - r.opy) * r.iy, yh = (gy - r.omy) * r.iy;
+    const float zl = (gz - r.opz) * r.iz, zh = (gz - r.omz) * r.iz;
+    const float xin = ux ? xl : xh, xout = ux ? xh : xl;
+    const float yin = uy ? yl : yh, yout = uy ? yh : yl;
+    const float zin = uz ? zl : zh, zout = uz ? zh : zl;
     uint32_t m = 0u;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int k = j & 3;
-        const float ax = fmaf(byte_of(j < 4 ? qa.x : qa.y, k), kx, x0), bx = fmaf(byte_of(j < 4 ? qb.z : qb.w, k), kx, x1);
-        const float ay = fmaf(byte_of(j < 4 ? qa.z : qa.w, k), ky, y0), by = fmaf(byte_of(j < 4 ? qc.x : qc.y, k), ky, y1);
-        const float az = fmaf(byte_of(j < 4 ? qb.x : qb.y, k), kz, z0), bz = fmaf(byte_of(j < 4 ? qc.z : qc.w, k), kz, z1);
-        const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const float t_in = fmaxf(fmaxf(fmaf(byte_of(j < 4 ? xi0 : xi1, k), kx, xin), fmaf(byte_of(j < 4 ? yi0 : yi1, k), ky, yin)),
+                                 fmaf(byte_of(j < 4 ? zi0 : zi1, k), kz, zin));
+        const float t_out = fminf(fminf(fmaf(byte_of(j < 4 ? xo0 : xo1, k), kx, xout), fmaf(byte_of(j < 4 ? yo0 : yo1, k), ky, yout)),
+                                  fmaf(byte_of(j < 4 ? zo0 : zo1, k), kz, zout));
         m |= (t_in <= t_out * 1.000001f && t_out >= 0.0f && t_in <= t_limit) ? (1u << j) : 0u;
     }
     return m & (h.w >> 24);

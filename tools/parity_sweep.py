@@ -23,7 +23,8 @@ def main():
     import test_gpu_parity as T
     families = {"search": T.test_random_scenes_search_is_conservative, "mirrors": T.test_random_scenes_with_mirrors,
                 "environment": T.test_random_scenes_inside_an_environment, "quadrics": T.test_random_scenes_with_quadrics,
-                "glass": T.test_random_glass_in_a_room, "textures": T.test_random_scenes_with_textures, "gather": T.test_random_scenes_gather}
+                "glass": T.test_random_glass_in_a_room, "textures": T.test_random_scenes_with_textures, "gather": T.test_random_scenes_gather,
+                "glass_spheres": T.glass_among_spheres_seeded}
     chosen = sys.argv[3:] or list(families)
     oracle = Oracle()
     failed = []
