@@ -1427,9 +1427,6 @@ __device__ __forceinline__ void walk_ray(const GeneralTable &t, const SceneView 
     uint32_t m = meets8_box(t.nodes, br, t_limit);
     n_pairs += 8u;
     while (true) {
-#ifdef WALK_STATS
-        n_pairs += 1000000u; // turns of the loop, in the millions digit and above
-#endif
         if (m == 0u) { // this group is done: back to what is left of the parent's
             if (lvl == 0) break;
             lvl--;
@@ -1548,13 +1545,6 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, SceneVie
         }
     }
     if (active) cand_cnt[rid] = odd ? CAND_UNSEARCHED : cnt;
-#ifdef WALK_STATS
-    { // counter 5: turns summed over lanes; counter 3: 64 x the wave's longest
-        const uint32_t turns = n_pairs / 1000000u;
-        wave_count(counters, 3, (uint32_t)wave_max_f((float)turns));
-        n_pairs = turns;
-    }
-#endif
     wave_count(counters, 5, n_pairs);
 }
 
@@ -2540,7 +2530,14 @@ __global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w, Gather ga)
 #define WALK_REFILL 16
 #endif
 #ifndef WALK_TURNS
-#define WALK_TURNS 2
+#define WALK_TURNS 3
+#endif
+#define WALK_HOLD 2u // leaves a lane can hold
+#ifndef WALK_TEST_MIN
+#define WALK_TEST_MIN 24u
+#endif
+#ifndef WALK_WAIT_MAX
+#define WALK_WAIT_MAX 8u
 #endif
 #ifndef WALK_WAVES
 #define WALK_WAVES 4 // waves per SIMD (128 registers): at 3 the frame takes a quarter longer, at 5 the spills cost more
@@ -2559,6 +2556,7 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
     uint32_t rid = 0u, base = 0u, m = 0u, n_pairs = 0u, n_exact = 0u, n_sent = 0u;
     int lvl = 0, bprim = -1;
     bool zero_tri = false;
+    uint32_t held = 0u, hold0 = 0u, hold1 = 0u; // leaves that passed the fp32 tests and wait for the fp64 one
     unsigned long long left = 0ull;
     Ray e;
     e.pe = D3(0, 0, 0); e.npe = D3(0, 0, 0);
@@ -2605,6 +2603,7 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
                     const float ul = ux * ux + uy * uy + uz * uz;
                     o_l1 = fabsf(ox) + fabsf(oy) + fabsf(oz);
                     bt = RT_FLT_MAX; bprim = -1; t_limit = 3.0e38f;
+                    held = 0u;
                     has = true;
                     if (!(ul > 0.99f && ul < 1.01f) || !(o_l1 < t.far_origin)) {
                         zero_tri = true; // a ray the table cannot answer for: everything is asked
@@ -2653,9 +2652,12 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
         }
 #pragma unroll 1
         for (int turn = 0; turn < WALK_TURNS; turn++) {
-            if (!has) continue;
+            if (!has || held == WALK_HOLD) continue;
             if (m == 0u) { // this group is done: back to what is left of the parent's
-                if (lvl == 0) { finish(); continue; }
+                if (lvl == 0) {
+                    if (held == 0u) finish(); // (a lane that still holds primitives waits for their tests below)
+                    continue;
+                }
                 lvl--;
                 base = (base >> 3) & ~7u;
                 m = (uint32_t)(left >> (8 * lvl)) & 0xffu;
@@ -2667,17 +2669,8 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
                 const float4 q = t.prim[node];
                 if (ray_meets(ox, oy, oz, ux, uy, uz, o_l1, q, t_limit) && // (again: the limit may have come down since)
                     ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, q, t.prim_n[node])) {
-                    const uint32_t id = t.prim_id[node];
-                    const double4 rec = s.prim_rec[id & CAND_INDEX];
-                    n_exact++;
-                    if (id & CAND_TRI) {
-                        int outside; d3 ph; double u, v;
-                        const double tc = tri_t(s.tris[__double2hiint(rec.x)], e, &outside, &ph, &u, &v);
-                        if (tc == 0) zero_tri = true; // also -0.0
-                        consider(tc, (int)(id & CAND_INDEX));
-                    } else {
-                        consider(sphere_t_rec(rec, e), (int)(id & CAND_INDEX));
-                    }
+                    if (held == 0u) hold0 = node; else hold1 = node;
+                    held++;
                 }
                 continue;
             }
@@ -2686,6 +2679,35 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
             base = node * 8u;
             m = meets8_box(t.nodes + (size_t)(level_offset(lvl) + base) / 8 * 4, br, t_limit);
             n_pairs += 8u;
+        }
+        // The fp64 tests of the primitives the lanes hold, for all lanes together: when enough of them hold one, or
+        // when lanes that cannot go on without theirs (both places taken, or the walk over) have become many, or
+        // when no lane can go on at all.
+        {
+            const bool holds = has && held > 0u;
+            const bool waits = has && (held == WALK_HOLD || (held > 0u && m == 0u && lvl == 0));
+            const uint32_t n_holds = (uint32_t)__popcll(__ballot(holds)), n_waits = (uint32_t)__popcll(__ballot(waits));
+            const uint32_t n_moving = (uint32_t)__popcll(__ballot(has && !waits));
+            if (n_holds >= WALK_TEST_MIN || n_waits >= WALK_WAIT_MAX || (n_waits > 0u && n_moving == 0u)) { // uniform
+                while (__any(holds && held > 0u)) {
+                    if (held > 0u) {
+                        const uint32_t id = t.prim_id[hold0];
+                        const double4 rec = s.prim_rec[id & CAND_INDEX];
+                        n_exact++;
+                        if (id & CAND_TRI) {
+                            int outside; d3 ph; double u, v;
+                            const double tc = tri_t(s.tris[__double2hiint(rec.x)], e, &outside, &ph, &u, &v);
+                            if (tc == 0) zero_tri = true; // also -0.0
+                            consider(tc, (int)(id & CAND_INDEX));
+                        } else {
+                            consider(sphere_t_rec(rec, e), (int)(id & CAND_INDEX));
+                        }
+                        hold0 = hold1;
+                        held--;
+                    }
+                }
+                if (has && m == 0u && lvl == 0) finish(); // the walk was over and only waited for these
+            }
         }
     }
     wave_count(w.counters, 5, n_pairs);
