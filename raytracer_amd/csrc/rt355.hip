@@ -3388,7 +3388,7 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     for (size_t m = 0; m * 8 < sorted.size(); m++, n_groups8++) mean_group += mini_rows[m].w;
     g.tight_rho = n_groups8 ? (float)(mean_group / (double)n_groups8) : 0.0f;
     g.tight_rho *= 2.0f;
-    g.tight_theta = 0.3f;
+    g.tight_theta = 0.15f;
     g.far_origin = (float)sc->view.far_origin;
     if (const char *e = getenv("RT355_GENERAL_TIGHT")) { // "rho_factor,theta": tuning aid
         double a = 1, b = 0.2;
