@@ -204,8 +204,8 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None
     # the reference's own classes (CalcIntersect, Shader::shading, Color ...) driven by the harness, one thread
     work = scene.n_primitives * (1 + len(shader.lights))
     rows = 64 if work < 200 else (1 if work < 200_000 else 0)
-    if shading:
-        rows = 16
+    if shading:  # (every gather ray tests every primitive: rows of a small scene only)
+        rows = 16 if scene.n_primitives * len(dirs) < 5000 else 0
     if Reference.available() and rows:
         R = Reference()
         o = B.opts(w, h, row_begin=h // 2, row_end=h // 2 + rows, shading=shading)
