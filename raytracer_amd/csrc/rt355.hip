@@ -2527,17 +2527,19 @@ __global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w, Gather ga)
 // walk over everything.  !BLEED only asks whether there is a hit (shader.h:130-133): after the first one only
 // what the ray's origin lies in is still looked at, for such a triangle.
 #ifndef WALK_REFILL
-#define WALK_REFILL 16
+#define WALK_REFILL 24
 #endif
 #ifndef WALK_TURNS
 #define WALK_TURNS 3
 #endif
-#define WALK_HOLD 2u // leaves a lane can hold
+#ifndef WALK_HOLD
+#define WALK_HOLD 8u // leaves a lane can hold
+#endif
 #ifndef WALK_TEST_MIN
-#define WALK_TEST_MIN 24u
+#define WALK_TEST_MIN 40u
 #endif
 #ifndef WALK_WAIT_MAX
-#define WALK_WAIT_MAX 8u
+#define WALK_WAIT_MAX 24u
 #endif
 #ifndef WALK_WAVES
 #define WALK_WAVES 4 // waves per SIMD (128 registers): at 3 the frame takes a quarter longer, at 5 the spills cost more
@@ -2556,7 +2558,8 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
     uint32_t rid = 0u, base = 0u, m = 0u, n_pairs = 0u, n_exact = 0u, n_sent = 0u;
     int lvl = 0, bprim = -1;
     bool zero_tri = false;
-    uint32_t held = 0u, hold0 = 0u, hold1 = 0u; // leaves that passed the fp32 tests and wait for the fp64 one
+    __shared__ uint32_t held_leaf[WALK_HOLD][256]; // the leaves whose boxes a lane's ray enters, waiting for their tests
+    uint32_t held = 0u;
     unsigned long long left = 0ull;
     Ray e;
     e.pe = D3(0, 0, 0); e.npe = D3(0, 0, 0);
@@ -2665,13 +2668,9 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
             }
             const uint32_t node = base + (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
-            if (lvl == last) {
-                const float4 q = t.prim[node];
-                if (ray_meets(ox, oy, oz, ux, uy, uz, o_l1, q, t_limit) && // (again: the limit may have come down since)
-                    ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, q, t.prim_n[node])) {
-                    if (held == 0u) hold0 = node; else hold1 = node;
-                    held++;
-                }
+            if (lvl == last) { // a leaf whose box the ray enters: held for the tests below
+                held_leaf[held][threadIdx.x] = node;
+                held++;
                 continue;
             }
             left = (left & ~(0xffull << (8 * lvl))) | ((unsigned long long)m << (8 * lvl));
@@ -2680,18 +2679,36 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
             m = meets8_box(t.nodes + (size_t)(level_offset(lvl) + base) / 8 * 4, br, t_limit);
             n_pairs += 8u;
         }
-        // The fp64 tests of the primitives the lanes hold, for all lanes together: when enough of them hold one, or
-        // when lanes that cannot go on without theirs (both places taken, or the walk over) have become many, or
-        // when no lane can go on at all.
+        // The tests of the leaves the lanes hold, for all lanes together: when enough of them hold one, or when
+        // lanes that cannot go on without theirs (all places taken, or the walk over) have become many, or when no
+        // lane can go on at all.  First the fp32 tests of all held leaves (the sphere, and a triangle's plane), then
+        // the fp64 tests of those that passed: a test made by the few lanes that happen to have reached a leaf in
+        // this turn would cost the whole wave its loads and its hundreds of fp64 instructions.
         {
             const bool holds = has && held > 0u;
             const bool waits = has && (held == WALK_HOLD || (held > 0u && m == 0u && lvl == 0));
             const uint32_t n_holds = (uint32_t)__popcll(__ballot(holds)), n_waits = (uint32_t)__popcll(__ballot(waits));
             const uint32_t n_moving = (uint32_t)__popcll(__ballot(has && !waits));
             if (n_holds >= WALK_TEST_MIN || n_waits >= WALK_WAIT_MAX || (n_waits > 0u && n_moving == 0u)) { // uniform
+                uint32_t passed = 0u;
+#pragma unroll 1
+                for (uint32_t k = 0; k < WALK_HOLD; k++) {
+                    if (k < held) {
+                        const uint32_t node = held_leaf[k][threadIdx.x];
+                        const float4 q = t.prim[node];
+                        if (ray_meets(ox, oy, oz, ux, uy, uz, o_l1, q, t_limit) && // (again: the limit may have come down since)
+                            ray_meets_plane_of(ox, oy, oz, ux, uy, uz, o_l1, q, t.prim_n[node])) {
+                            held_leaf[passed][threadIdx.x] = node;
+                            passed++;
+                        }
+                    }
+                    if (!__any(k + 1 < held)) break; // uniform
+                }
+                held = passed;
                 while (__any(holds && held > 0u)) {
                     if (held > 0u) {
-                        const uint32_t id = t.prim_id[hold0];
+                        held--;
+                        const uint32_t id = t.prim_id[held_leaf[held][threadIdx.x]];
                         const double4 rec = s.prim_rec[id & CAND_INDEX];
                         n_exact++;
                         if (id & CAND_TRI) {
@@ -2702,8 +2719,6 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
                         } else {
                             consider(sphere_t_rec(rec, e), (int)(id & CAND_INDEX));
                         }
-                        hold0 = hold1;
-                        held--;
                     }
                 }
                 if (has && m == 0u && lvl == 0) finish(); // the walk was over and only waited for these
