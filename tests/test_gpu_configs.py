@@ -165,6 +165,33 @@ def test_searched_gather_without_lights(api, oracle):
     r.close()
 
 
+def test_searched_gather_at_full_size(api, oracle):
+    """HEAD's renderer (CalcSubPixel2 + shading3 / shading2) on the 100 000-triangle scene at 3840x2160, 42
+    directions: 87 million gather rays through the scene table in one launch.  Every 64th pixel in x and y against
+    the checker (which tests every triangle for every ray), ray counts of the sample's rows aside; the two shaders;
+    eight shares of interleaved row tiles against the frame rendered at once."""
+    scene, sh, cam, w, h = bench.build_workload("mesh100k_bleed42_4k")
+    shading, dirs = bench.gather_of("mesh100k_bleed42_4k")
+    packed = scene.pack()
+    r = api.Renderer(packed)
+    r.set_directions(dirs)
+    stride = 64
+    for shade in (shading, B.SHADING_OCCLUSION):
+        frame, st = r.render(cam, sh, w, h, shading=shade)
+        assert st["primary_rays"] == w * h and st["gather_rays"] > 80_000_000 and st["shadow_rays"] == 0
+        want, wst = oracle.render(packed, cam, sh, B.opts(w, h, shading=shade), threads=0, stride=stride, dirs=dirs)
+        a, b = frame[::stride, ::stride], want[::stride, ::stride]
+        ndiff = int((a != b).any(axis=2).sum())
+        assert ndiff == 0, f"{ndiff} of {a.shape[0] * a.shape[1]} sampled pixels differ from the CPU checker"
+    tiles = np.zeros_like(frame)
+    gathered = 0
+    for g in range(8):
+        _, pst = r.render(cam, sh, w, h, shading=B.SHADING_OCCLUSION, out=tiles, tile_rows=32, tile_count=8, tile_phase=g)
+        gathered += pst["gather_rays"]
+    assert np.array_equal(tiles, frame) and gathered == st["gather_rays"]
+    r.close()
+
+
 def test_interleaved_row_tiles_small(api, oracle):
     """rt355_opts.tile_*: the shares of the interleaved row tiles reproduce the frame, whatever the tile height,
     the number of shares (more shares than tiles included) and the renderer: lights, supersampling, mirrors
