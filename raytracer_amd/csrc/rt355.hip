@@ -1427,12 +1427,13 @@ __device__ __forceinline__ void walk_ray(const GeneralTable &t, const SceneView 
     uint32_t m = meets8_box(t.nodes, br, t_limit);
     n_pairs += 8u;
     while (true) {
-        if (m == 0u) { // this group is done: back to what is left of the parent's
-            if (lvl == 0) break;
-            lvl--;
-            base = (base >> 3) & ~7u;
-            m = (uint32_t)(left >> (8 * lvl)) & 0xffu;
-            continue;
+        if (m == 0u) { // this group is done: straight back to the deepest level that has siblings left
+            const unsigned long long below = lvl > 0 ? (left & ((1ull << (8 * lvl)) - 1ull)) : 0ull;
+            if (below == 0ull) break;
+            const int up = (63 - __builtin_clzll(below)) >> 3;
+            m = (uint32_t)(below >> (8 * up)) & 0xffu;
+            base = (base >> (3 * (lvl - up))) & ~7u;
+            lvl = up;
         }
         const uint32_t node = base + (uint32_t)__builtin_ctz(m);
         m &= m - 1u;
@@ -2656,28 +2657,40 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
 #pragma unroll 1
         for (int turn = 0; turn < WALK_TURNS; turn++) {
             if (!has || held == WALK_HOLD) continue;
-            if (m == 0u) { // this group is done: back to what is left of the parent's
-                if (lvl == 0) {
-                    if (held == 0u) finish(); // (a lane that still holds primitives waits for their tests below)
+            // A turn is priced by its most expensive lane, the one that enters a node, so every lane should enter
+            // one: leaves are put among the held ones and finished groups are left on the way, both in a few
+            // instructions -- the way back goes straight to the deepest level that has siblings left.
+            auto hold_leaves = [&]() {
+                while (m != 0u && held < WALK_HOLD) {
+                    held_leaf[held][threadIdx.x] = base + (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    held++;
+                }
+            };
+            if (lvl == last) {
+                hold_leaves();
+                if (m != 0u) continue; // no place left: on after the tests below
+            }
+            if (m == 0u) {
+                const unsigned long long below = lvl > 0 ? (left & ((1ull << (8 * lvl)) - 1ull)) : 0ull;
+                if (below == 0ull) { // the walk is over (a lane that still holds leaves waits for their tests below)
+                    lvl = 0;
+                    if (held == 0u) finish();
                     continue;
                 }
-                lvl--;
-                base = (base >> 3) & ~7u;
-                m = (uint32_t)(left >> (8 * lvl)) & 0xffu;
-                continue;
+                const int up = (63 - __builtin_clzll(below)) >> 3;
+                m = (uint32_t)(below >> (8 * up)) & 0xffu;
+                base = (base >> (3 * (lvl - up))) & ~7u;
+                lvl = up;
             }
             const uint32_t node = base + (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
-            if (lvl == last) { // a leaf whose box the ray enters: held for the tests below
-                held_leaf[held][threadIdx.x] = node;
-                held++;
-                continue;
-            }
             left = (left & ~(0xffull << (8 * lvl))) | ((unsigned long long)m << (8 * lvl));
             lvl++;
             base = node * 8u;
             m = meets8_box(t.nodes + (size_t)(level_offset(lvl) + base) / 8 * 4, br, t_limit);
             n_pairs += 8u;
+            if (lvl == last) hold_leaves();
         }
         // The tests of the leaves the lanes hold, for all lanes together: when enough of them hold one, or when
         // lanes that cannot go on without theirs (all places taken, or the walk over) have become many, or when no
