@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -139,6 +140,11 @@ struct Frame {
     // pixmap half written by workgroups that run on other XCDs).
     int32_t deferred;
     int32_t soft; // RT355_SHADING_SOFT: Shader::shading calls CalcSoftShadow (shader.h:91) in place of CalcShadow (:90)
+    // The last stage of a searched frame (last light group's shading, the fold of the levels, k_average) can be
+    // launched part by part, whole rows of tiles each, so that the readback of a part runs while the next is shaded:
+    // first ray of this launch of a per-ray kernel, first local row of this launch of k_average.
+    uint32_t rid_base;
+    int32_t avg_row0;
 };
 // row of the frame that local row `y` of the call is (local rows are the rows rendered, in order)
 __device__ __forceinline__ int frame_row(const Frame &f, int y) {
@@ -1805,7 +1811,7 @@ __device__ __forceinline__ void direct_store(unsigned char *__restrict__ pixmap,
 // pixels of a row and writes them as 48 dwords.
 __global__ __launch_bounds__(256) void k_average(Frame f, const uint32_t *__restrict__ sub,
                                                  unsigned char *__restrict__ pixmap) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = f.avg_row0 + (int)blockIdx.y;
     const bool valid = x < f.width && y < f.rows;
     uint32_t out = 0u;
     if (valid && f.alias <= 0) {
@@ -2885,7 +2891,7 @@ __global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, 
 
 // clr * (1 - ks) + CalcSubPixel(mirror ray) * ks from the deepest level back (main.cpp:109), then the pixel
 __global__ __launch_bounds__(256) void k_fold_levels(Frame f, Work w, unsigned char *__restrict__ pixmap) {
-    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rid = f.rid_base + blockIdx.x * blockDim.x + threadIdx.x;
     if (rid >= f.n_rays) return;
     int x, y;
     rid_to_xy(rid, f.tiles_x, &x, &y);
@@ -2948,7 +2954,7 @@ __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, F
 template <bool ENV, bool SOFT = false>
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView s, ShaderView sh, Frame f, Work w, Group cur,
                                                      Group next, unsigned char *__restrict__ pixmap) {
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rid = f.rid_base + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_eval = 0, n_over = 0, n_soft = 0;
 #ifdef RT355_DEBUG_SURVIVORS
     uint32_t dbg_n[LIGHT_GROUP] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3793,11 +3799,21 @@ static int ensure_gather(rt355_scene *sc, size_t live_rows) {
 // same statistics and are waited for as one: `first` clears the counters and uploads the lights, `last` closes
 // the frame (rt355_render reads every part back while the next one renders).
 struct PartOfFrame { bool first, last; };
+// How rt355_render takes a searched frame's pixels back while the frame is still being shaded: the last stage of the
+// frame (the shading of the last group of lights, the fold of the mirror levels, k_average) is launched in `n_parts`
+// parts of whole tile rows, and after each part `copy_rows(ya, yb)` is called for the local rows it completed in the
+// device framebuffer.  The last part's pixels go to `last_direct` instead (the caller's page-locked pixmap as the
+// device sees it), when that is given: no later kernel would overlap its transfer.
+struct TailParts {
+    int n_parts;
+    unsigned char *last_direct;
+    std::function<int(int, int)> copy_rows;
+};
 // One frame (or slab) enqueued on `hip_stream`.  noalloc: the entry point that allocates nothing -- the counters,
 // the lights and the sub-sample colours live in the static array, and frames that need the workspace are refused.
 static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                           const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats, bool noalloc,
-                          PartOfFrame part = PartOfFrame{true, true}) {
+                          PartOfFrame part = PartOfFrame{true, true}, const TailParts *tail = nullptr) {
     if (!sc || !cam || !shader || !opts || !d_pixmap) return fail(RT355_ERR_ARG, "rt355_render_device: null argument");
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
     if (opts->alias < 0 || opts->alias > 64) return fail(RT355_ERR_ARG, "alias must be 0..64");
@@ -3835,6 +3851,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     f.n_rays = (uint32_t)n_rays64;
     f.level = -1;
     f.deferred = 0;
+    f.rid_base = 0; f.avg_row0 = 0;
     const int nl = shader->n_lights;
     const int slots = slots_for(f.n_rays, nl);
     const int n_groups = (nl + slots - 1) / slots;
@@ -4112,6 +4129,38 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         if (part.last) HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
     }
     int resolves = 0;
+    // The last stage in parts (see TailParts): part p covers tile rows [tiles_y p / n, tiles_y (p + 1) / n).  Not for
+    // supersampled frames (a pixel's sub-samples span tile rows), shares of interleaved tiles, or the gather shaders
+    // (whose last stage is a blend that costs nothing).
+    const int tail_parts = (tail && can_search && !gather_searched && f.alias == 0 && f.tile_count <= 1)
+                               ? std::max(1, std::min(tail->n_parts, f.tiles_y)) : 1;
+    bool tail_done = false;
+    // the part of the last turn, whose transfer no kernel overlaps, is half as high as the others
+    const bool tail_top_first = !getenv("RT355_TAIL_BOTTOM_FIRST");
+    auto tail_tile_row = [&](int p) {
+        if (tail_parts == 1 || getenv("RT355_TAIL_EVEN")) return (int)((int64_t)f.tiles_y * p / tail_parts);
+        const int64_t halves = 2 * tail_parts - 1;
+        const int64_t before = tail_top_first ? std::max(0, 2 * p - 1) : std::min<int64_t>(2 * p, halves); // half-heights below part p
+        return (int)(f.tiles_y * before / halves);
+    };
+    auto tail_first_rid = [&](int p) { return (uint32_t)tail_tile_row(p) * (uint32_t)f.tiles_x * (uint32_t)RAYS_PER_TILE; };
+    // fold and pixels of part p, then its rows handed to the caller
+    // The parts are taken from the top of the frame down: the transfers are the longer side of most frames' last
+    // stage, so it ends soonest when they start soonest -- with the cheapest part first, and where a frame has sky it
+    // has it at the top.
+    auto tail_part_of_turn = [&](int turn) { return tail_top_first ? tail_parts - 1 - turn : turn; };
+    auto tail_finish = [&](int p, bool last_turn) -> int {
+        const int ya = tail_tile_row(p) * TILE_H, yb = std::min(f.rows, tail_tile_row(p + 1) * TILE_H);
+        Frame fp = f;
+        fp.rid_base = tail_first_rid(p);
+        fp.avg_row0 = ya;
+        if (levels)
+            hipLaunchKernelGGL(k_fold_levels, dim3((tail_first_rid(p + 1) - fp.rid_base) / 256u), dim3(256), 0, st, fp, w, pix);
+        const bool direct = last_turn && tail->last_direct;
+        hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)(yb - ya)), dim3(256), 0, st, fp, w.rec_sum,
+                           direct ? tail->last_direct : pix);
+        return direct ? RT355_OK : tail->copy_rows(ya, yb);
+    };
     // one level of the frame: the search of its rays (camera rays: the eye's tables; mirror rays: the scene table),
     // the fp64 closest hit and hit record, then the lights group by group
     auto run_level = [&](int L) -> int {
@@ -4167,12 +4216,27 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             if ((rc1 = clear_bins(next))) return rc1;
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
             hipLaunchKernelGGL(k_shade_far, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur);
-            if (soft)
-                hipLaunchKernelGGL((k_shade_group<true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
-            else if (sc->view.n_envs + sc->view.n_quadrics > 0)
-                hipLaunchKernelGGL(k_shade_group<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
-            else
-                hipLaunchKernelGGL(k_shade_group<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur, next, pix);
+            // the frame's last shading launch goes part by part when the caller reads the parts back meanwhile (the
+            // time recorded for it then includes the parts' folds and k_average launches)
+            const bool in_parts = tail_parts > 1 && L == extra_levels && j == n_groups - 1;
+            for (int turn = 0; turn < (in_parts ? tail_parts : 1); turn++) {
+                const int p = tail_part_of_turn(turn);
+                Frame fp = fl;
+                unsigned blocks = per_ray_blocks;
+                if (in_parts) {
+                    fp.rid_base = tail_first_rid(p);
+                    blocks = (tail_first_rid(p + 1) - fp.rid_base) / 256u;
+                    if (blocks == 0) continue; // (a frame of fewer tile rows than parts)
+                }
+                if (soft)
+                    hipLaunchKernelGGL((k_shade_group<true, true>), dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
+                else if (sc->view.n_envs + sc->view.n_quadrics > 0)
+                    hipLaunchKernelGGL(k_shade_group<true>, dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
+                else
+                    hipLaunchKernelGGL(k_shade_group<false>, dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
+                if (in_parts && (rc1 = tail_finish(p, turn == tail_parts - 1))) return rc1;
+            }
+            if (in_parts) tail_done = true;
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
             resolves++;
             cur = next;
@@ -4225,10 +4289,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             hipLaunchKernelGGL(k_reflect_rays, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, dc, f, w, L);
             if ((rc = run_level(L + 1))) return rc;
         }
-        if (levels) hipLaunchKernelGGL(k_fold_levels, dim3(per_ray_blocks), dim3(256), 0, st, f, w, pix);
+        if (levels && !tail_done) hipLaunchKernelGGL(k_fold_levels, dim3(per_ray_blocks), dim3(256), 0, st, f, w, pix);
     }
-    if (f.alias > 0 || f.deferred)
+    if ((f.alias > 0 || f.deferred) && !tail_done)
         hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
+    if (tail && !tail_done && (rc = tail->copy_rows(0, f.rows))) return rc; // (a frame whose last stage is one launch: all rows at once)
     HIP_TRY(hipGetLastError());
     sc->pending_primary += (uint64_t)f.grid_w * (uint64_t)f.grid_h;
     if (!part.last) return RT355_OK;
@@ -4411,19 +4476,24 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     const bool refract = sc->refractive && (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
     const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
     const bool one_kernel = opts->tile_count <= 1 && !searched;
+    // a searched frame whose last stage can be launched in parts, each read back while the next is shaded (TailParts)
+    const bool tail_way = searched && opts->tile_count <= 1 && opts->alias == 0 && !getenv("RT355_NO_TAIL_PARTS") &&
+                          (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
     // A page-locked pixmap is mapped into the device's address space, and the kernels that write the pixels can
     // write them there, whole dwords in row order: the transfer over PCIe then runs while the frame is rendered
     // and no readback step is left.  Measured on MI355X at 3840x2160: k_average streams a searched frame's pixels
     // out at the 55 GB/s the copy engine reaches; a one-kernel frame's own stores reach 40 GB/s, which beats
     // rendering and copying in parts when the kernel runs longer than the transfer (glass room 0.97 against 1.14
-    // ms, mirrors 1.11 against 1.18) and loses when it is shorter (the default scene 0.61 against 0.53).  Which it
+    // ms, mirrors 1.11 against 1.18) and loses when it is shorter (the default scene 0.61 against 0.53).  A searched
+    // frame's last stage in four parts, each copied while the next is shaded, beats k_average writing the whole frame
+    // across at the end (10 000 spheres 3.44 against 3.67 ms, the 100 000-triangle mesh 1.49 against 1.75).  Which it
     // is the handle finds out by timing its calls on the host: the first READBACK_PROBES frames of a kind (size,
     // shader, lights) go one way and the other in turn, the frames after them the way whose last call was shorter,
     // and every READBACK_RETRY-th frame the other way once more (the first frames of a process are slow either way,
     // and what the link to the host gives changes while a process runs).  The event the call waits on orders the
     // writes before the caller's reads.  (RT355_READBACK_COPY / RT355_READBACK_DIRECT force one way.)
     bool direct = pinned, timing = false;
-    if (pinned && one_kernel) {
+    if (pinned && (one_kernel || tail_way)) {
         uint64_t key = 0x9e3779b97f4a7c15ull;
         for (uint64_t v : {(uint64_t)opts->width, (uint64_t)opts->height, (uint64_t)rows.y0, (uint64_t)rows.y1, (uint64_t)opts->alias,
                            (uint64_t)opts->shading, (uint64_t)opts->mode, (uint64_t)(shader ? shader->n_lights : 0), (uint64_t)sc->n_dirs})
@@ -4462,7 +4532,8 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     }
     // parts: whole multiples of 32 rows (the tile height of the ray numbering divides it), at least 256 rows each;
     // a call that renders a share of interleaved row tiles is one part
-    // a searched frame is a chain of a dozen launches whose cost does not shrink with the rows: one part
+    // a searched frame is a chain of a dozen launches whose cost does not shrink with the rows: it is enqueued once,
+    // and only its last stage comes in parts (tail_way below)
     int n_parts = 1;
     if (one_kernel) {
         n_parts = 6;
@@ -4509,6 +4580,29 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // stream, as soon as its kernel has finished, while the later parts render.
     int rc = RT355_OK;
     int n_copies = 0; // parts whose transfer was enqueued
+    int copy_ya[RENDER_PARTS_MAX], copy_yb[RENDER_PARTS_MAX]; // ... and their rows
+    if (tail_way) { // one enqueue; its last stage comes in parts, and each part's rows are read back as it completes
+        TailParts tp;
+        tp.n_parts = 4;
+        if (const char *e = getenv("RT355_TAIL_PARTS")) tp.n_parts = atoi(e);
+        tp.n_parts = std::max(1, std::min(tp.n_parts, RENDER_PARTS_MAX));
+        void *mapped = nullptr;
+        if (!(last_direct && tp.n_parts > 1 && hipHostGetDevicePointer(&mapped, pixmap, 0) == hipSuccess && mapped)) {
+            (void)hipGetLastError();
+            mapped = nullptr;
+        }
+        tp.last_direct = (unsigned char *)mapped;
+        tp.copy_rows = [&](int ya, int yb) -> int {
+            if (n_copies >= RENDER_PARTS_MAX) return fail(RT355_ERR_ARG, "internal: more readback parts than events");
+            const int i = n_copies;
+            copy_ya[i] = rows.y0 + ya; copy_yb[i] = rows.y0 + yb;
+            const int rc1 = read_back(copy_ya[i], copy_yb[i], sc->ev_part[i], sc->ev_copy[i], (two_streams && (i & 1)) ? sc->copy_stream2 : sc->copy_stream);
+            if (rc1 == RT355_OK) n_copies = i + 1;
+            return rc1;
+        };
+        rc = render_enqueue(sc, cam, shader, opts, sc->fb, nullptr, stats, false, PartOfFrame{true, true}, &tp);
+        n_parts = 0;
+    }
     for (int i = 0; i < n_parts && rc == RT355_OK; i++) {
         rt355_opts part = *opts;
         part.row_begin = part_y0[i]; part.row_end = part_y0[i + 1];
@@ -4519,12 +4613,12 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         }
         rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, stats, false, PartOfFrame{i == 0, i == n_parts - 1});
         if (rc == RT355_OK) rc = read_back(part_y0[i], part_y0[i + 1], sc->ev_part[i], sc->ev_copy[i], (two_streams && (i & 1)) ? sc->copy_stream2 : sc->copy_stream);
-        if (rc == RT355_OK) n_copies = i + 1;
+        if (rc == RT355_OK) { copy_ya[i] = part_y0[i]; copy_yb[i] = part_y0[i + 1]; n_copies = i + 1; }
     }
     for (int i = 0; i < n_copies && rc == RT355_OK && !pinned; i++) { // staged parts -> the pixmap, each as it arrives
         hipError_t e = hipEventSynchronize(sc->ev_copy[i]);
         if (e != hipSuccess) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
-        else to_pixmap(part_y0[i], part_y0[i + 1]);
+        else to_pixmap(copy_ya[i], copy_yb[i]);
     }
     // (on an error too: no transfer into the caller's memory may outlive the call)
     hipError_t e = hipStreamSynchronize(sc->copy_stream);

@@ -231,8 +231,15 @@ def test_host_pixmap_paths_agree(api):
     an unsearched one, and rt355_render_device: the same bytes and ray counts; a second, smaller frame on the
     same handle reuses the framebuffer."""
     import os
-    for case in ("spheres300", "default_2lights"):
-        sc, sh, cam, _, _ = S.small_case(case)
+    for case in ("spheres300", "default_2lights", "mirror_spheres"):
+        if case == "mirror_spheres":  # searched, with mirror levels: the last stage of the frame holds a fold
+            sc = S.spheres_scene(200, seed=94)
+            for i, o in enumerate(sc.objects):
+                if o["type"] == B.OBJ_PLANE or i % 3 == 0:
+                    o["ks"] = 0.5
+            sh = S.Shader(S.ring_lights(2), 0x101010, 0xDDDDDD, 0x202020)
+        else:
+            sc, sh, cam, _, _ = S.small_case(case)
         r = api.Renderer(sc)
         for w, h in ((640, 1100), (322, 300)):
             cam = S.default_camera(w, h)
@@ -241,14 +248,15 @@ def test_host_pixmap_paths_agree(api):
             _, hst = r.render(cam, sh, w, h, out=host.array)   # the kernels write into the mapped pixmap
             assert np.array_equal(host.array, dev)
             for parts in ("1", "3", "8"):
-                os.environ["RT355_RENDER_PARTS"] = parts
+                os.environ["RT355_RENDER_PARTS"] = parts        # parts of a one-kernel frame
+                os.environ["RT355_TAIL_PARTS"] = parts          # parts of a searched frame's last stage
                 os.environ["RT355_READBACK_COPY"] = "1"         # ... or into HBM, and the copy engine reads back
                 try:
                     pageable, pst = r.render(cam, sh, w, h)
                     host.array[:] = 0
                     _, cst = r.render(cam, sh, w, h, out=host.array)
                 finally:
-                    del os.environ["RT355_RENDER_PARTS"], os.environ["RT355_READBACK_COPY"]
+                    del os.environ["RT355_RENDER_PARTS"], os.environ["RT355_TAIL_PARTS"], os.environ["RT355_READBACK_COPY"]
                 assert np.array_equal(pageable, dev) and np.array_equal(host.array, dev), parts
                 for k in ("primary_rays", "shadow_rays", "primary_hits", "exact_tests"):
                     assert pst[k] == hst[k] == cst[k] == dst[k], (parts, k)
