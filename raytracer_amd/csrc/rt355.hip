@@ -3155,7 +3155,9 @@ struct rt355_scene {
     uint64_t readback_key = 0;     // rt355_render: the kind of frame the choice below was made for (0: none yet)
     uint64_t readback_frames = 0;  // ... frames of that kind rendered so far
     double debug_ms[2] = {0, 0}; uint64_t debug_calls[2] = {0, 0}; // RT355_DEBUG_READBACK: call time summed per way
-    double readback_ms[2] = {0, 0}; // ... what the last call took each way: [0] direct, [1] copied in parts (ms of wall time)
+    std::vector<float> debug_series;                               // ... and every call's (negative: the direct way)
+    double readback_ms[2][3] = {{0, 0, 0}, {0, 0, 0}}; // ... what the last three calls took each way: [0] direct, [1] copied in parts (ms of wall time)
+    uint32_t readback_calls[2] = {0, 0};                // ... and how many calls went each way
     std::vector<hipEvent_t> ev_copy, ev_part; // per part of a frame: its rows have arrived / have been rendered
     rt355_stats *pending_stats = nullptr;
     hipStream_t pending_stream = nullptr;
@@ -3539,6 +3541,7 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     kind_prims.insert(kind_prims.end(), by_kind[4].begin(), by_kind[4].end());
     kind_prims.insert(kind_prims.end(), by_kind[2].begin(), by_kind[2].end());
     rt355_scene *sc = new rt355_scene();
+    if (getenv("RT355_DEBUG_READBACK")) sc->debug_series.reserve(4096);
     // everything after `new` runs inside one function, so that any failure takes the one cleanup path below
     auto init = [&]() -> int {
     HIP_TRY(hipGetDevice(&sc->device));
@@ -3630,6 +3633,11 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
         fprintf(stderr, "[rt355] rt355_render calls: %llu direct, mean %.3f ms; %llu copied in parts, mean %.3f ms\n",
                 (unsigned long long)sc->debug_calls[0], sc->debug_ms[0] / (double)std::max<uint64_t>(1, sc->debug_calls[0]),
                 (unsigned long long)sc->debug_calls[1], sc->debug_ms[1] / (double)std::max<uint64_t>(1, sc->debug_calls[1]));
+    if (!sc->debug_series.empty()) {
+        fprintf(stderr, "[rt355] rt355_render call times (ms, negative: written directly):");
+        for (float v : sc->debug_series) fprintf(stderr, " %.2f", v);
+        fprintf(stderr, "\n");
+    }
     (void)hipSetDevice(sc->device);
     if (sc->pending && sc->pending_stream != nullptr) (void)hipStreamSynchronize(sc->pending_stream);
     else (void)hipDeviceSynchronize();
@@ -4447,7 +4455,7 @@ static bool host_is_pinned(const void *p) { // page-locked memory the runtime kn
 // is filled from page-locked staging memory, the host copy of a part overlapping the transfer of the next.
 // Nothing is allocated per frame: framebuffer and staging grow when a larger frame comes and are kept.
 #define RENDER_PARTS_MAX 8
-#define READBACK_PROBES 6
+#define READBACK_PROBES 8
 #define READBACK_RETRY 32
 extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                             const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats) {
@@ -4488,9 +4496,9 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // frame's last stage in four parts, each copied while the next is shaded, beats k_average writing the whole frame
     // across at the end (10 000 spheres 3.44 against 3.67 ms, the 100 000-triangle mesh 1.49 against 1.75).  Which it
     // is the handle finds out by timing its calls on the host: the first READBACK_PROBES frames of a kind (size,
-    // shader, lights) go one way and the other in turn, the frames after them the way whose last call was shorter,
-    // and every READBACK_RETRY-th frame the other way once more (the first frames of a process are slow either way,
-    // and what the link to the host gives changes while a process runs).  The event the call waits on orders the
+    // shader, lights) go one way and the other in turn, the frames after them the way whose shortest of its last
+    // three calls was shorter, and every READBACK_RETRY-th frame the other way once more (the first frames of a
+    // process are slow either way, and what the link to the host gives changes while a process runs).  The event the call waits on orders the
     // writes before the caller's reads.  (RT355_READBACK_COPY / RT355_READBACK_DIRECT force one way.)
     bool direct = pinned, timing = false;
     if (pinned && (one_kernel || tail_way)) {
@@ -4499,8 +4507,13 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
                            (uint64_t)opts->shading, (uint64_t)opts->mode, (uint64_t)(shader ? shader->n_lights : 0), (uint64_t)sc->n_dirs})
             key = (key ^ v) * 0x100000001b3ull;
         key |= 1ull;
-        if (sc->readback_key != key) { sc->readback_key = key; sc->readback_frames = 0; }
-        const bool faster_direct = sc->readback_ms[0] <= sc->readback_ms[1];
+        if (sc->readback_key != key) { sc->readback_key = key; sc->readback_frames = 0; sc->readback_calls[0] = sc->readback_calls[1] = 0; }
+        auto recent = [&](int way) { // the shortest of the way's last three calls: one slow call (a first use, a busy host) decides nothing
+            double best = 1e30;
+            for (uint32_t i = 0; i < std::min(sc->readback_calls[way], 3u); i++) best = std::min(best, sc->readback_ms[way][i]);
+            return best;
+        };
+        const bool faster_direct = recent(0) <= recent(1);
         if (sc->readback_frames < READBACK_PROBES) direct = (sc->readback_frames & 1) == 0;
         else direct = (sc->readback_frames % READBACK_RETRY == 0) ? !faster_direct : faster_direct;
         timing = true;
@@ -4510,10 +4523,13 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     auto timed = [&](int rc) { // a call has ended
         if (!timing) return rc;
         if (rc != RT355_OK) { sc->readback_key = 0; return rc; }
-        sc->readback_ms[direct ? 0 : 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        const int way = direct ? 0 : 1;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        sc->readback_ms[way][sc->readback_calls[way]++ % 3u] = ms;
         sc->readback_frames++;
-        sc->debug_ms[direct ? 0 : 1] += sc->readback_ms[direct ? 0 : 1];
-        sc->debug_calls[direct ? 0 : 1]++;
+        sc->debug_ms[way] += ms;
+        sc->debug_calls[way]++;
+        if (sc->debug_series.capacity() > sc->debug_series.size()) sc->debug_series.push_back((float)(direct ? -ms : ms)); // (reserved when asked for: no allocation here)
         return rc;
     };
     if (direct) {

@@ -18,6 +18,12 @@ r = Renderer(scene)
 if dirs is not None:
     r.set_directions(dirs)
 host = HostPixmap(w, h)
+if os.environ.get("PRIME"):  # device-to-host copies of another buffer first: is the slow start the copy engine's or this pixmap's?
+    src = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda")
+    dst = torch.zeros(w * h * 3, dtype=torch.uint8).pin_memory()
+    for _ in range(int(os.environ["PRIME"])):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
 ms = []
 for _ in range(n):
     t0 = time.perf_counter()
