@@ -319,27 +319,34 @@ def measure(name, args, ctx):
             return count_rays(st), st
     elif cams is not None:
         mine = frames_for_rank(len(cams), rank, world) if world > 1 else list(range(len(cams)))
-        # A frame is a chain of a dozen dependent launches, so one frame at a time leaves the GPU waiting at every
-        # link; a sweep has many frames to draw, and `in_flight` scene handles, each with its own stream and its own
-        # page-locked pixmap (written by the frame's last kernel itself), keep that many of them going at once.
+        # rt355_render_sweep: frame f on rank f mod N, every frame with its own camera (the eye's tables are rebuilt)
+        # and its own page-locked pixmap; the library reads a frame back while it renders the next.  With
+        # --in-flight 2 the rank's frames are dealt to two scene handles, each sweeping its share from a host thread
+        # of its own (the calls block; ctypes releases the interpreter lock), which also fills the gaps between one
+        # handle's frames.
+        import threading
         n_fly = max(1, min(args.in_flight, len(mine)))
-        fly = [(r, host, torch.cuda.Stream())] + [(Renderer(scene), HostPixmap(w, h), torch.cuda.Stream()) for _ in range(n_fly - 1)]
+        sweep_pix = [HostPixmap(w, h) for _ in mine]
+        fly = [r] + [Renderer(scene) for _ in range(n_fly - 1)]
         extra_handles = fly[1:]
+        shares = [list(range(k, len(mine), n_fly)) for k in range(n_fly)]
 
         def step():
-            rays, st, busy = 0.0, None, [False] * n_fly
-            for i, f in enumerate(mine):  # frame f on rank f mod N; every frame moves the camera (the eye's tables are rebuilt)
-                rr, hp, s_ = fly[i % n_fly]
-                if busy[i % n_fly]:
-                    st = rr.sync()        # this handle's last frame is complete in its pixmap (here a consumer would take it)
-                    rays += count_rays(st)
-                rr.render_device(cams[f], shader, o, hp.device_ptr, s_.cuda_stream)
-                busy[i % n_fly] = True
-            for k in range(n_fly):
-                if busy[(len(mine) + k) % n_fly]:
-                    st = fly[(len(mine) + k) % n_fly][0].sync()
-                    rays += count_rays(st)
-            return rays, st
+            out = [None] * n_fly
+
+            def run(k):
+                out[k] = fly[k].render_sweep([cams[mine[i]] for i in shares[k]], shader, o, [sweep_pix[i].array for i in shares[k]])
+            threads = [threading.Thread(target=run, args=(k,)) for k in range(1, n_fly)]
+            for t in threads:
+                t.start()
+            run(0)
+            for t in threads:
+                t.join()
+            if any(s_ is None for s_ in out):
+                raise RuntimeError("a sweep thread failed")
+            rays = sum(count_rays(st) for sts in out for st in sts)
+            last_k = (len(mine) - 1) % n_fly
+            return rays, out[last_k][-1]
     else:
         # the call itself and nothing else in the loop: arguments and the statistics record are made once, the
         # rays of a step are counted from the record after the loop (every frame of this workload casts the same)
@@ -389,10 +396,10 @@ def measure(name, args, ctx):
             stats = dict(stats, **{k: int(v) for k, v in zip(keys, rays_all[1:].tolist())})
     if cams is not None:
         # the frame the sweep ends on lies in the pixmap of the handle that drew it
-        last_host = fly[(len(mine) - 1) % n_fly][1]
-        gpu_last = last_host.array.copy()
-        for rr, hp, _ in extra_handles:
+        gpu_last = sweep_pix[-1].array.copy()
+        for rr in extra_handles:
             rr.close()
+        for hp in sweep_pix:
             hp.close()
     if rank != 0:
         r.close()
@@ -421,7 +428,7 @@ def measure(name, args, ctx):
     out = {"value": round(value, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4),
            "timed": ("rt355_render_device of this rank's rows + gather of the final frame on rank 0 + its readback" if split else
-                     ("rt355_render_device into page-locked host pixmaps, frames in flight on scene handles of their own" if cams is not None else
+                     ("rt355_render_sweep into page-locked host pixmaps, one per frame (readback included)" if cams is not None else
                       "rt355_render into a page-locked host pixmap (readback of the frame included)")),
            "scaling": "strong" if fixed_total else "weak",
            "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives,

@@ -313,6 +313,14 @@ void rt355_host_free(void *p);
  * flight, and rt355_scene_sync(handle) tells when a handle's frame is complete. */
 void *rt355_host_device_pointer(void *p);
 
+/* A camera sweep: frame i is rendered with cams[i] into pixmaps[i] (host memory, each as for rt355_render), all with
+ * the same shader and options; stats, if not NULL, receives n_frames records.  The same pixels as n_frames calls of
+ * rt355_render, but the transfer of a frame to the host runs while the next frame is rendered.
+ * Replaces: setPixels (main.cpp:339-376) called once per camera -- the call at main.cpp:640 inside a loop that moves
+ * Scene's camera fields (main.cpp:529-541) between frames; the reference itself renders one frame per run. */
+int rt355_render_sweep(rt355_scene *scene, const rt355_camera *cams, int32_t n_frames, const rt355_shader *shader,
+                       const rt355_opts *opts, unsigned char *const *pixmaps, rt355_stats *stats);
+
 /* Wait for the scene's outstanding render and fill the stats passed to it. */
 int rt355_scene_sync(rt355_scene *scene);
 

@@ -42,6 +42,7 @@ def lib():
         L.rt355_scene_destroy.restype = None
         L.rt355_render.argtypes = [C.c_void_p] * 6
         L.rt355_render_device.argtypes = [C.c_void_p] * 7
+        L.rt355_render_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt355_render_device_noalloc.argtypes = [C.c_void_p] * 7
         L.rt355_host_alloc.restype = C.c_void_p
         L.rt355_host_alloc.argtypes = [C.c_uint64]
@@ -99,6 +100,16 @@ class Renderer:
         _check(lib().rt355_render(self.handle, C.byref(cam), C.byref(shader.c), C.byref(o), out.ctypes.data,
                                   C.byref(st)), "rt355_render")
         return out, st.as_dict()
+
+    def render_sweep(self, cams, shader: Shader, o: COpts, pixmaps):
+        """rt355_render_sweep: frame i with cams[i] into pixmaps[i] ((H, W, 3) uint8 arrays, page-locked or not).
+        Returns the list of the frames' stats dicts."""
+        n = len(cams)
+        cam_arr = (type(cams[0]) * n)(*cams) if n else None
+        ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in pixmaps])
+        st = (CStats * n)()
+        _check(lib().rt355_render_sweep(self.handle, cam_arr, n, C.byref(shader.c), C.byref(o), ptrs, st), "rt355_render_sweep")
+        return [s.as_dict() for s in st]
 
     def set_directions(self, dirs):
         """The direction set `geo` of the gather shaders (main.cpp:639), (n, 3) float64 as Geodesic() leaves it."""

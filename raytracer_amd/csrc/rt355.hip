@@ -3149,8 +3149,10 @@ struct rt355_scene {
     // rt355_render (host pixmap): the device framebuffer kept from call to call, the stream the readback runs on
     // beside the rendering of the next part of the frame, and page-locked staging for pixmaps that are pageable
     unsigned char *fb = nullptr; size_t fb_bytes = 0;
+    unsigned char *fb2 = nullptr; size_t fb2_bytes = 0; // rt355_render_sweep: the framebuffer of every other frame
     unsigned char *stage = nullptr; size_t stage_bytes = 0;
     hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;
+    hipStream_t sweep_stream = nullptr; // rt355_render_sweep renders on a stream of the handle's own
     double last_ms = 0;            // device time of the last frame (rt355_scene_sync)
     uint64_t readback_key = 0;     // rt355_render: the kind of frame the choice below was made for (0: none yet)
     uint64_t readback_frames = 0;  // ... frames of that kind rendered so far
@@ -3652,7 +3654,9 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (sc->host_counters) (void)hipHostFree(sc->host_counters);
     if (sc->copy_stream) { (void)hipStreamSynchronize(sc->copy_stream); (void)hipStreamDestroy(sc->copy_stream); }
     if (sc->copy_stream2) { (void)hipStreamSynchronize(sc->copy_stream2); (void)hipStreamDestroy(sc->copy_stream2); }
+    if (sc->sweep_stream) { (void)hipStreamSynchronize(sc->sweep_stream); (void)hipStreamDestroy(sc->sweep_stream); }
     if (sc->fb) (void)hipFree(sc->fb);
+    if (sc->fb2) (void)hipFree(sc->fb2);
     if (sc->stage) (void)hipHostFree(sc->stage);
     for (hipEvent_t e : sc->ev_copy) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->ev_part) (void)hipEventDestroy(e);
@@ -4646,6 +4650,97 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         if (rc == RT355_OK) rc = rc_sync;
     }
     return timed(rc);
+}
+
+// A camera sweep: setPixels once per camera (main.cpp:640 in a loop over cameras), frame i into pixmaps[i].  Frames
+// alternate between two framebuffers in HBM; the rows of frame i travel to the host on the copy stream while frame
+// i + 1 is rendered, so that of all the transfers only the last one is not hidden.  A pageable pixmap is filled from
+// the page-locked staging memory once its transfer has arrived (the next transfer waits for that copy).
+extern "C" int rt355_render_sweep(rt355_scene *sc, const rt355_camera *cams, int32_t n_frames, const rt355_shader *shader,
+                                  const rt355_opts *opts, unsigned char *const *pixmaps, rt355_stats *stats) {
+    if (!sc || !opts || n_frames < 0 || (n_frames && (!cams || !pixmaps))) return fail(RT355_ERR_ARG, "rt355_render_sweep: bad argument");
+    if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
+    for (int i = 0; i < n_frames; i++)
+        if (!pixmaps[i]) return fail(RT355_ERR_ARG, "rt355_render_sweep: null pixmap");
+    if (n_frames == 0) return RT355_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    Rows rows;
+    { int rc0 = rows_of(opts, &rows); if (rc0) return rc0; }
+    const size_t row_bytes = (size_t)opts->width * 3, bytes = row_bytes * (size_t)opts->height;
+    if (sc->pending) { int rc0 = rt355_scene_sync(sc); if (rc0) return rc0; }
+    if (bytes > sc->fb_bytes) {
+        if (sc->fb) { (void)hipFree(sc->fb); sc->fb = nullptr; sc->fb_bytes = 0; }
+        HIP_TRY(hipMalloc((void **)&sc->fb, bytes));
+        sc->fb_bytes = bytes;
+    }
+    if (bytes > sc->fb2_bytes) {
+        if (sc->fb2) { (void)hipFree(sc->fb2); sc->fb2 = nullptr; sc->fb2_bytes = 0; }
+        HIP_TRY(hipMalloc((void **)&sc->fb2, bytes));
+        sc->fb2_bytes = bytes;
+    }
+    if (!sc->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream, hipStreamNonBlocking));
+    if (!sc->sweep_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->sweep_stream, hipStreamNonBlocking));
+    const hipStream_t st = sc->sweep_stream; // (two handles sweeping from two host threads then overlap on the GPU)
+    while (sc->ev_copy.size() < 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sc->ev_copy.push_back(e);
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sc->ev_part.push_back(e);
+    }
+    bool any_pageable = false;
+    for (int i = 0; i < n_frames; i++) any_pageable = any_pageable || !host_is_pinned(pixmaps[i]);
+    if (any_pageable && bytes > sc->stage_bytes) {
+        if (sc->stage) { (void)hipHostFree(sc->stage); sc->stage = nullptr; sc->stage_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&sc->stage, bytes, hipHostMallocDefault));
+        sc->stage_bytes = bytes;
+    }
+    // the rows this call renders, as ranges of frame rows (a share of interleaved tiles: one range per tile)
+    std::vector<std::pair<int, int>> ranges;
+    if (opts->tile_count > 1) {
+        for (int k = opts->tile_phase; k * opts->tile_rows < rows.y1 - rows.y0; k += opts->tile_count)
+            ranges.push_back({rows.y0 + k * opts->tile_rows, std::min(rows.y1, rows.y0 + (k + 1) * opts->tile_rows)});
+    } else {
+        ranges.push_back({rows.y0, rows.y1});
+    }
+    int staged = -1; // the frame whose rows lie in the staging memory, still to be copied into its pageable pixmap
+    auto unstage = [&]() -> int {
+        if (staged < 0) return RT355_OK;
+        hipError_t e = hipEventSynchronize(sc->ev_copy[staged & 1]);
+        if (e != hipSuccess) return fail(RT355_ERR_DEVICE, std::string("rt355_render_sweep: ") + hipGetErrorString(e));
+        for (const auto &r : ranges)
+            memcpy(pixmaps[staged] + r.first * row_bytes, sc->stage + r.first * row_bytes, (size_t)(r.second - r.first) * row_bytes);
+        staged = -1;
+        return RT355_OK;
+    };
+    int rc = RT355_OK;
+    for (int i = 0; i < n_frames && rc == RT355_OK; i++) {
+        unsigned char *fb = (i & 1) ? sc->fb2 : sc->fb;
+        // frame i - 2 has left this framebuffer before frame i is rendered into it
+        if (i >= 2) {
+            hipError_t e = hipStreamWaitEvent(st, sc->ev_copy[i & 1], 0);
+            if (e != hipSuccess) { rc = fail(RT355_ERR_DEVICE, std::string("rt355_render_sweep: ") + hipGetErrorString(e)); break; }
+        }
+        rc = render_enqueue(sc, &cams[i], shader, opts, fb, st, stats ? &stats[i] : nullptr, false); // (waits for frame i - 1's statistics first)
+        if (rc != RT355_OK) break;
+        const bool pinned = host_is_pinned(pixmaps[i]);
+        if (!pinned && (rc = unstage()) != RT355_OK) break; // the staging memory is free again
+        unsigned char *dst = pinned ? pixmaps[i] : sc->stage;
+        hipError_t e = hipEventRecord(sc->ev_part[i & 1], st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(sc->copy_stream, sc->ev_part[i & 1], 0);
+        for (size_t k = 0; k < ranges.size() && e == hipSuccess; k++)
+            e = hipMemcpyAsync(dst + ranges[k].first * row_bytes, fb + ranges[k].first * row_bytes,
+                               (size_t)(ranges[k].second - ranges[k].first) * row_bytes, hipMemcpyDeviceToHost, sc->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(sc->ev_copy[i & 1], sc->copy_stream);
+        if (e != hipSuccess) { rc = fail(RT355_ERR_DEVICE, std::string("rt355_render_sweep: ") + hipGetErrorString(e)); break; }
+        if (!pinned) staged = i;
+    }
+    // (on an error too: no transfer into the caller's memory may outlive the call)
+    if (sc->pending) { const int rc_sync = rt355_scene_sync(sc); if (rc == RT355_OK) rc = rc_sync; }
+    if (rc == RT355_OK) rc = unstage();
+    hipError_t e = hipStreamSynchronize(sc->copy_stream);
+    if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("rt355_render_sweep: ") + hipGetErrorString(e));
+    return rc;
 }
 
 extern "C" int rt355_scene_set_directions(rt355_scene *sc, const double *xyz, int32_t n) {

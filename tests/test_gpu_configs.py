@@ -144,8 +144,46 @@ def test_camera_sweep_of_the_triangle_scene(api, oracle):
             finish(k)
     fly[1][0].close()
     fly[1][1].close()
+    # the same frames by rt355_render_sweep: one call, the readback of a frame running while the next is rendered
+    pix = [api.HostPixmap(w, h) for _ in mine]
+    sts = r.render_sweep([cams[f] for f in mine], sh, B.opts(w, h), [p.array for p in pix])
+    for f, p, st in zip(mine, pix, sts):
+        assert np.array_equal(p.array, frames[f]) and st["shadow_rays"] == rays[f], f
+        p.close()
     host.close()
     r.close()
+
+
+def test_sweep_entry_point(api):
+    """rt355_render_sweep against rt355_render frame by frame: page-locked and pageable pixmaps (and both in one
+    call), a searched scene and an unsearched one, whole frames, a row slab and a share of interleaved tiles (rows
+    outside the call's share stay untouched), zero frames and one."""
+    for case, (w, h) in (("spheres300", (200, 150)), ("default_2lights", (161, 97))):
+        sc, sh, _, _, _ = S.small_case(case)
+        r = api.Renderer(sc)
+        cams = [S.orbit_camera(f, w, h, n_frames=7, center=(0.0, 40.0, 0.0), radius=60.0) for f in range(7)]
+        assert r.render_sweep([], sh, B.opts(w, h), []) == []
+        for kw in ({}, {"row_begin": 40, "row_end": 90}, {"tile_rows": 16, "tile_count": 3, "tile_phase": 1}):
+            want = []
+            for c in cams:
+                out = np.full((h, w, 3), 7, dtype=np.uint8)
+                _, st = r.render(c, sh, w, h, out=out, **kw)
+                want.append((out, st))
+            for n, pinned in ((7, "all"), (7, "none"), (7, "mixed"), (1, "all")):
+                hosts = [api.HostPixmap(w, h) for _ in range(n)]
+                pix = []
+                for i, hp in enumerate(hosts):
+                    a = hp.array if (pinned == "all" or (pinned == "mixed" and i % 3 != 1)) else np.empty((h, w, 3), dtype=np.uint8)
+                    a[:] = 7
+                    pix.append(a)
+                sts = r.render_sweep(cams[:n], sh, B.opts(w, h, **kw), pix)
+                for i in range(n):
+                    assert np.array_equal(pix[i], want[i][0]), (case, kw, pinned, i)
+                    for k in ("primary_rays", "shadow_rays", "primary_hits", "exact_tests"):
+                        assert sts[i][k] == want[i][1][k], (case, kw, pinned, i, k)
+                for hp in hosts:
+                    hp.close()
+        r.close()
 
 
 def test_searched_gather_without_lights(api, oracle):
