@@ -461,6 +461,19 @@ def measure(name, args, ctx):
     out["value_device_resident"] = round(rays_dev / dt1 / 1e6, 2)
     out["ms_per_step_device_resident"] = round(dt1 * 1e3 / args.steps, 4)
     assert np.array_equal(fb.cpu().numpy(), gpu_frame), "rt355_render and rt355_render_device gave different frames"
+    # ---- what this box's link to the host gives: the same frame copied from HBM to the page-locked pixmap and nothing
+    # else (the floor of `ms_per_step` minus the rendering that the copy cannot overlap; boxes differ by a factor of 2)
+    host_t = torch.from_numpy(host.array)
+    for _ in range(3):
+        host_t.copy_(fb, non_blocking=True)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(10):
+        host_t.copy_(fb, non_blocking=True)
+    torch.cuda.synchronize()
+    copy_ms = (time.perf_counter() - t2) * 1e2
+    out["readback"] = {"bytes_per_frame": w * h * 3, "plain_copy_ms": round(copy_ms, 4),
+                       "link_GBps": round(w * h * 3 / (copy_ms * 1e-3) / 1e9, 1)}
     n_rays_padded = ((w + 31) // 32) * ((h + 31) // 32) * 1024
     # ---- kernel-time breakdown: a few more frames, HIP-event times read back after each
     K = 3
@@ -669,7 +682,7 @@ def main():
                "higher_is_better": True, "scaling": head["scaling"],
                "vs_baseline": None, "dtype": "f64" if head["config"]["primitives"] < 64 else "f32 search + f64 resolve",
                "data": "synthetic"}
-        for k in ("timed", "value_device_resident", "ms_per_step_device_resident", "config", "kernel_time", "roofline",
+        for k in ("timed", "value_device_resident", "ms_per_step_device_resident", "readback", "config", "kernel_time", "roofline",
                   "roofline_other_kernels", "all_pairs", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]

@@ -101,6 +101,12 @@ __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, u
 #ifndef CAND_BATCH
 #define CAND_BATCH 2        // candidates whose ids and records are loaded together by the exact tests
 #endif
+#ifndef SHADE_SKIP
+#define SHADE_SKIP 0        // 1: the shading kernel leaves out the highlight and the shadow mix where they change nothing (measured: no gain)
+#endif
+#ifndef SHADE_PREFETCH
+#define SHADE_PREFETCH 2    // the shading kernel asks for the next light's candidate count (1), first ids (2) and their records (3) ahead of time
+#endif
 #define SEARCH_MIN_PRIMS 64 // below this the fp64 brute-force walk is cheaper than a search
 
 // ---- rid <-> pixel -------------------------------------------------------------------------------
@@ -1568,15 +1574,18 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, SceneVie
 // POSITIVE: the gather loops' rule, an object's hit counts only with t > 0 (shader.h:130,176).
 // PRUNED: the candidates come from walk_ray, which stops at the closest hit it knows of: should a mesh be removed,
 // what lies beyond was never listed, and the ray goes to the ordered walk over everything.
+// What a kernel loads ahead of time for a ray's exact tests: the candidate count, the first CAND_BATCH ids and (the
+// shading kernel with SHADE_PREFETCH 3) their records.
+struct Pre { uint32_t n; uint32_t id[CAND_BATCH]; double4 rec[CAND_BATCH]; };
 template <bool POSITIVE = false, bool ENV = true, bool PRUNED = false>
 __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                             uint32_t n_rays, const uint32_t *__restrict__ cand,
                                             const uint32_t *__restrict__ cand_cnt, const Spill &sp, Closest &c,
-                                            uint32_t &evaluated, uint32_t &overflowed) {
+                                            uint32_t &evaluated, uint32_t &overflowed, const Pre *pre = nullptr) {
     c.init();
     uint32_t n = 0, n_spill = 0;
     if (!brute) {
-        n = cand_cnt[rid];
+        n = pre ? pre->n : cand_cnt[rid];
         if (n == CAND_UNSEARCHED) { brute = true; n = 0; }
         else if (n > CAND_CAP) { // the rest is in the bundle's spill list, unless that overflowed too
             overflowed += 1;
@@ -1624,7 +1633,8 @@ __device__ __forceinline__ void closest_hit(const SceneView &s, const Ray &e, bo
                 uint32_t id[CAND_BATCH];
                 double4 rec[CAND_BATCH];
 #pragma unroll
-                for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n_own) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
+                for (int j = 0; j < CAND_BATCH; j++)
+                    id[j] = (k0 + j < n_own) ? ((pre && k0 == 0) ? pre->id[j] : cp[(size_t)(k0 + j) * n_rays]) : 0u;
 #pragma unroll
                 for (int j = 0; j < CAND_BATCH; j++) rec[j] = s.prim_rec[id[j] & CAND_INDEX];
 #pragma unroll
@@ -1671,8 +1681,9 @@ template <bool ENV = true>
 __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray &e, bool brute, uint32_t rid,
                                                    uint32_t n_rays, const uint32_t *__restrict__ cand,
                                                    const uint32_t *__restrict__ cand_cnt, const Spill &sp,
-                                                   uint32_t &evaluated, uint32_t &overflowed) {
-    const uint32_t n = brute ? 0u : cand_cnt[rid];
+                                                   uint32_t &evaluated, uint32_t &overflowed,
+                                                   const Pre *pre = nullptr) {
+    const uint32_t n = brute ? 0u : (pre ? pre->n : cand_cnt[rid]);
     bool general = brute || n > CAND_CAP;
     double bt = RT_FLT_MAX;
     if (!general) {
@@ -1681,9 +1692,11 @@ __device__ __forceinline__ double nearest_occluder(const SceneView &s, const Ray
             uint32_t id[CAND_BATCH];
             double4 rec[CAND_BATCH];
 #pragma unroll
-            for (int j = 0; j < CAND_BATCH; j++) id[j] = (k0 + j < n) ? cp[(size_t)(k0 + j) * n_rays] : 0u;
+            for (int j = 0; j < CAND_BATCH; j++)
+                id[j] = (k0 + j < n) ? ((SHADE_PREFETCH >= 2 && pre && k0 == 0) ? pre->id[j] : cp[(size_t)(k0 + j) * n_rays]) : 0u;
 #pragma unroll
-            for (int j = 0; j < CAND_BATCH; j++) rec[j] = s.prim_rec[id[j] & CAND_INDEX];
+            for (int j = 0; j < CAND_BATCH; j++)
+                rec[j] = (SHADE_PREFETCH >= 3 && pre && k0 == 0) ? pre->rec[j] : s.prim_rec[id[j] & CAND_INDEX];
 #pragma unroll
             for (int j = 0; j < CAND_BATCH; j++) {
                 if (k0 + j >= n) break;
@@ -2947,7 +2960,7 @@ __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, F
 // the shadow (shader.h:75-89), CalcShadow on the light's candidates (shader.h:393-433), the running
 // mean (shader.h:93); then either the next group's shadow rays or the pixel store (main.cpp:367-369).
 #ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 4 // waves per SIMD the shading kernel's register budget allows
+#define SHADE_MIN_WAVES 3 // waves per SIMD the shading kernel's register budget allows
 #endif
 // ENV: the scene holds an Environment or a quadric (their tests are compiled out otherwise).  SOFT: CalcSoftShadow
 // (every shadow ray goes through the fp64 walk over everything: `cur` holds no searched bundle).
@@ -2989,14 +3002,39 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     uint32_t sum = cur.k0 ? w.rec_sum[rid] : 0u, unused = 0;
     // (the rays of the levels after the camera rays' are cast by the recursion, which passes neither m nor n)
     const SoftArgs soft = (SOFT && f.level <= 0) ? soft_args(f, x, y) : SoftArgs{0, 0.0, 0.0};
+    // The candidate count and the first ids of light g + 1 are asked for before light g is shaded: count -> ids ->
+    // records -> test is a chain of three dependent loads per light otherwise, and with four waves on a SIMD there
+    // is little else to run meanwhile.  (Slots past the count hold stale ids of the workspace: loaded, never used.)
+    Pre pre_a, pre_b, pre; // the light after next (count, ids), the next light (+ records), this light
+    auto fetch_ids = [&](int g, Pre &dst) {
+        dst.n = 0u;
+#pragma unroll
+        for (int j = 0; j < CAND_BATCH; j++) dst.id[j] = 0u;
+        if (SOFT || g >= cur.count || cur.b[g].kind == 0) return; // uniform
+        dst.n = w.cand_cnt[(size_t)g * n + rid];
+        if (SHADE_PREFETCH < 2) return;
+        const uint32_t *cp = w.cand + (size_t)g * CAND_CAP * n + rid;
+#pragma unroll
+        for (int j = 0; j < CAND_BATCH; j++) dst.id[j] = cp[(size_t)j * n];
+    };
+    auto fetch_recs = [&](Pre &dst) { // (ids past the count are stale ids of the workspace, or 0: any of them names a record)
+#pragma unroll
+        for (int j = 0; j < CAND_BATCH; j++) dst.rec[j] = s.prim_rec[min(dst.id[j] & CAND_INDEX, (uint32_t)(s.n_prims - 1))];
+    };
+    if (SHADE_PREFETCH) fetch_ids(0, pre_b);
+    if (SHADE_PREFETCH >= 3) { fetch_ids(1, pre_a); fetch_recs(pre_b); }
     for (int g = 0; g < cur.count; g++) {
-        sum = shade_light<SOFT, false>(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
+        pre = pre_b;
+        if (SHADE_PREFETCH >= 3) { pre_b = pre_a; fetch_recs(pre_b); fetch_ids(g + 2, pre_a); }
+        else if (SHADE_PREFETCH) fetch_ids(g + 1, pre_b);
+        sum = shade_light<SOFT, SHADE_SKIP != 0>(sh, cur.k0 + g, h, sum, [&](const Ray &sr) {
             Spill sp; sp.pool = w.spill.pool + (size_t)g * POOL_STRIDE(n); sp.count = w.spill.count + g;
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
-            return nearest_occluder<ENV>(s, sr, SOFT || cur.b[g].kind == 0, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
-                                    w.cand_cnt + (size_t)g * n, sp, n_eval, n_over);
+            const bool brute = SOFT || cur.b[g].kind == 0;
+            return nearest_occluder<ENV>(s, sr, brute, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
+                                    w.cand_cnt + (size_t)g * n, sp, n_eval, n_over, (brute || !SHADE_PREFETCH) ? nullptr : &pre);
         }, SOFT ? n_soft : unused, soft.m, soft.n);
     }
     if (last) {
