@@ -1,11 +1,14 @@
 #!/bin/bash
 # Every committed profile of the bench workloads in one go (GPU box): kernel traces, the HBM traffic passes, the SQ
 # passes of the dominant kernels and the all-pairs search.  Results land in gpurun_out/ named <round>_*; copy the
-# .txt summaries and the traffic file into profiles/.  Usage: bash tools/refresh_profiles.sh r2
+# .txt summaries and the traffic file into profiles/.  Usage: bash tools/refresh_profiles.sh r2 [traces|counters]
+# (the two halves fit one GPU call each)
 set -o pipefail
 R=${1:-r2}
+HALF=${2:-all}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
+if [ "$HALF" != "counters" ]; then
 for p in "trace_default default_4k" "trace_spheres10k spheres10k_8lights_4k" "trace_mesh100k mesh100k_2lights_4k" \
          "trace_bleed162 default_bleed162_4k" "trace_mirrors10k spheres10k_mirrors_8lights_4k" \
          "trace_glass glass_room_4k" "trace_default_mirrors default_mirrors_4k" "trace_mesh1m_8k mesh1m_2lights_8k" \
@@ -18,6 +21,8 @@ done
 bash tools/trace_pass.sh ${R}_trace_mesh100k_allpairs mesh100k_2lights_4k --mode allpairs > /dev/null || exit 1
 bash tools/pmc_pass.sh ${R}_pmc_mesh100k_allpairs_sq mesh100k_2lights_4k --mode allpairs -- SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU > /dev/null || exit 1
 echo "done allpairs" >> gpurun_out/refresh_progress.txt
+fi
+[ "$HALF" = "traces" ] && exit 0
 bash tools/traffic_passes.sh default_4k spheres10k_8lights_4k mesh100k_2lights_4k default_bleed162_4k glass_room_4k default_mirrors_4k > /dev/null || exit 1
 cp gpurun_out/traffic.json gpurun_out/${R}_traffic.json
 echo "done traffic" >> gpurun_out/refresh_progress.txt

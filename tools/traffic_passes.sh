@@ -7,7 +7,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-export RT355_READBACK_COPY=1 RT355_RENDER_PARTS=1
+export RT355_READBACK_COPY=1 RT355_RENDER_PARTS=1 RT355_TAIL_PARTS=1
 for wl in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     tag=traffic_${wl}_$c
