@@ -442,6 +442,11 @@ def measure(name, args, ctx):
                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
                       "packet_survivors": stats["packet_survivors"]}}
     if world > 1:  # the breakdowns below describe one GPU rendering whole frames
+        if split:  # the frame the ranks assembled against the same frame rendered by this rank alone (outside the timed region)
+            r.render_device(cam, shader, o, fb.data_ptr(), stream)
+            r.sync()
+            out["gathered_frame"] = "ok" if np.array_equal(fb.cpu().numpy(), gpu_frame) else "DIFFERS"
+            assert out["gathered_frame"] == "ok", "the frame gathered from the ranks differs from the frame one rank renders"
         r.close()
         host.close()
         return out
@@ -682,7 +687,7 @@ def main():
                "higher_is_better": True, "scaling": head["scaling"],
                "vs_baseline": None, "dtype": "f64" if head["config"]["primitives"] < 64 else "f32 search + f64 resolve",
                "data": "synthetic"}
-        for k in ("timed", "value_device_resident", "ms_per_step_device_resident", "readback", "config", "kernel_time", "roofline",
+        for k in ("timed", "gathered_frame", "value_device_resident", "ms_per_step_device_resident", "readback", "config", "kernel_time", "roofline",
                   "roofline_other_kernels", "all_pairs", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]
