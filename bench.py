@@ -284,7 +284,7 @@ def measure(name, args, ctx):
     import torch
     from raytracer_amd import binding as B
     from raytracer_amd.api import HostPixmap, Renderer
-    from raytracer_amd.sharding import frames_for_rank, gather_frame, rows_of, TILE_ROWS
+    from raytracer_amd.sharding import SharedPixmap, frames_for_rank, gather_frame, rows_of, TILE_ROWS
     dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
 
     scene, shader, cam, w, h = build_workload(name)
@@ -301,6 +301,7 @@ def measure(name, args, ctx):
     host = HostPixmap(w, h)  # page-locked, in place of `new unsigned char[width * height * 3]` (main.cpp:544)
     fb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
 
+    shared = None
     if split:
         if shard == "tiles":
             o_part = B.opts(w, h, mode=mode, shading=shading, tile_rows=TILE_ROWS, tile_count=world, tile_phase=rank)
@@ -308,8 +309,24 @@ def measure(name, args, ctx):
             b, e = rows_of(h, world, rank, "slabs")[0]
             o_part = B.opts(w, h, row_begin=b, row_end=e, mode=mode, shading=shading)
         host_t = torch.from_numpy(host.array)
+        shared = SharedPixmap(w, h, rank, world, dist) if args.gather == "host" else None
+        if shared is not None:
+            import ctypes as C
+            from raytracer_amd.api import lib, _check
+            from raytracer_amd.binding import CStats
+            rt355_render, st_part = lib().rt355_render, CStats()
+            part_args = (r.handle, C.byref(cam), C.byref(shader.c), C.byref(o_part), shared.array.ctypes.data, C.byref(st_part))
 
         def step():
+            if shared is not None:
+                # this rank's rows straight into the one pixmap all ranks share, over this GPU's own link to the host;
+                # the frame is complete when every rank's rows have arrived
+                rc = rt355_render(*part_args)
+                if rc:
+                    _check(rc, "rt355_render")
+                dist.barrier()
+                st = st_part.as_dict()
+                return count_rays(st), st
             # this rank's rows into its framebuffer in HBM, the final frame gathered on rank 0 (RCCL), read back there
             r.render_device(cam, shader, o_part, fb.data_ptr(), stream)
             st = r.sync()
@@ -402,6 +419,8 @@ def measure(name, args, ctx):
         for hp in sweep_pix:
             hp.close()
     if rank != 0:
+        if shared is not None:
+            shared.close()
         r.close()
         host.close()
         return None
@@ -424,10 +443,15 @@ def measure(name, args, ctx):
     ms_per_step = dt * 1e3 / args.steps
     value = rays_step * args.steps / dt / 1e6
     gpu_frame = gpu_last if cams is not None else host.array.copy()  # the last frame of the timed region, as the caller received it
+    shared_registered = shared is not None and shared.registered
+    if shared is not None:
+        gpu_frame = shared.array.copy()
+        shared.close()
     fixed_total = split or (cams is not None and world > 1)
     out = {"value": round(value, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4),
-           "timed": ("rt355_render_device of this rank's rows + gather of the final frame on rank 0 + its readback" if split else
+           "timed": (("rt355_render of this rank's rows into the one host pixmap all ranks share" + ("" if shared_registered else " (pageable: through each rank's staging memory)") + " + barrier" if args.gather == "host" else
+                      "rt355_render_device of this rank's rows + gather of the final frame on rank 0 + its readback") if split else
                      ("rt355_render_sweep into page-locked host pixmaps, one per frame (readback included)" if cams is not None else
                       "rt355_render into a page-locked host pixmap (readback of the frame included)")),
            "scaling": "strong" if fixed_total else "weak",
@@ -627,6 +651,9 @@ def main():
     ap.add_argument("--workload", default=HEADLINE)
     ap.add_argument("--shard", choices=["frames", "slabs", "tiles"], default=None,
                     help="N > 1: whole frames per rank (default), or one frame in row slabs / interleaved 32-row tiles")
+    ap.add_argument("--gather", choices=["host", "xgmi"], default="host",
+                    help="--shard slabs|tiles: where the frame comes together -- host: every rank writes its rows into one "
+                         "shared page-locked pixmap over its own link; xgmi: rows gathered on GPU 0 (RCCL) and read back there")
     ap.add_argument("--mode", choices=["packet", "allpairs"], default="packet",
                     help="search of searched scenes: packet = beams against a direction-sorted table "
                          "(library default); allpairs = fp32 test of every ray/primitive pair")

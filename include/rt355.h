@@ -307,6 +307,12 @@ int rt355_render_device_noalloc(rt355_scene *scene, const rt355_camera *cam,
  * of a host copy.  No counterpart in the reference. */
 void *rt355_host_alloc(uint64_t bytes);
 void rt355_host_free(void *p);
+/* Page-lock memory the caller already has -- the `new unsigned char[width * height * 3]` of main.cpp:544 left as it
+ * is, or a pixmap in memory that several processes share (one rank per GPU, every rank's rt355_render writing its
+ * rows of the one frame) -- for the current device; rt355_render then treats it like memory of rt355_host_alloc.
+ * Unregister before the memory is freed.  No counterpart in the reference. */
+int rt355_host_register(void *p, uint64_t bytes);
+int rt355_host_unregister(void *p);
 /* The address at which the device reaches a buffer of rt355_host_alloc (NULL for any other pointer): passed to
  * rt355_render_device as d_pixmap it makes the frame arrive in host memory without a copy and without the call
  * waiting for it -- several scene handles, each on its own stream, then keep several frames of a camera sweep in

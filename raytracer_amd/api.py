@@ -48,6 +48,8 @@ def lib():
         L.rt355_host_alloc.argtypes = [C.c_uint64]
         L.rt355_host_free.restype = None
         L.rt355_host_free.argtypes = [C.c_void_p]
+        L.rt355_host_register.argtypes = [C.c_void_p, C.c_uint64]
+        L.rt355_host_unregister.argtypes = [C.c_void_p]
         L.rt355_host_device_pointer.restype = C.c_void_p
         L.rt355_host_device_pointer.argtypes = [C.c_void_p]
         L.rt355_scene_sync.argtypes = [C.c_void_p]

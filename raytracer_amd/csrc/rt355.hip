@@ -3118,8 +3118,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
+        if (e_ != hipSuccess) {                                                               \
+            (void)hipGetLastError(); /* (reported here: a later call must not find it again) */ \
             return fail(RT355_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                     \
     } while (0)
 
 namespace {
@@ -4479,6 +4481,16 @@ extern "C" void *rt355_host_alloc(uint64_t bytes) {
     return p;
 }
 extern "C" void rt355_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int rt355_host_register(void *p, uint64_t bytes) {
+    if (!p || !bytes) return fail(RT355_ERR_ARG, "rt355_host_register: null pointer or no bytes");
+    HIP_TRY(hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped));
+    return RT355_OK;
+}
+extern "C" int rt355_host_unregister(void *p) {
+    if (!p) return fail(RT355_ERR_ARG, "rt355_host_unregister: null pointer");
+    HIP_TRY(hipHostUnregister(p));
+    return RT355_OK;
+}
 extern "C" void *rt355_host_device_pointer(void *p) {
     void *mapped = nullptr;
     if (!p || hipHostGetDevicePointer(&mapped, p, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -4491,13 +4503,44 @@ static bool host_is_pinned(const void *p) { // page-locked memory the runtime kn
     return attr.type == hipMemoryTypeHost;
 }
 
+#define RENDER_PARTS_MAX 8
+// The streams and events of the readback (rt355_render, rt355_render_sweep), made at a handle's first such call.
+static int ensure_readback(rt355_scene *sc) {
+    const bool first_call = !sc->copy_stream2;
+    if (!sc->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream, hipStreamNonBlocking));
+    if (!sc->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream2, hipStreamNonBlocking));
+    while (sc->ev_copy.size() < RENDER_PARTS_MAX) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sc->ev_copy.push_back(e);
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sc->ev_part.push_back(e);
+    }
+    if (first_call && !getenv("RT355_NO_COPY_PRIME") && sc->fb) {
+        // The runtime grows what it keeps per transfer in flight the first time a process has had some dozens of them
+        // (one call of 6 ms somewhere among a handle's first ten frames, measured); a burst of small transfers between
+        // events, as a frame's parts make them, has that happen here, in the call that sets the handle up anyway.
+        if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; } // (host_counters is the burst's target)
+        const int n = 96;
+        for (int i = 0; i < n; i++) {
+            hipStream_t cs = (i & 1) ? sc->copy_stream2 : sc->copy_stream;
+            HIP_TRY(hipEventRecord(sc->ev_part[i % RENDER_PARTS_MAX], nullptr));
+            HIP_TRY(hipStreamWaitEvent(cs, sc->ev_part[i % RENDER_PARTS_MAX], 0));
+            HIP_TRY(hipMemcpyAsync(sc->host_counters, sc->fb, 64, hipMemcpyDeviceToHost, cs));
+            HIP_TRY(hipEventRecord(sc->ev_copy[i % RENDER_PARTS_MAX], cs));
+        }
+        HIP_TRY(hipStreamSynchronize(sc->copy_stream));
+        HIP_TRY(hipStreamSynchronize(sc->copy_stream2));
+    }
+    return RT355_OK;
+}
+
 // setPixels' replacement (main.cpp:339-376): render into the handle's device framebuffer, read back into the
 // caller's pixmap.  The frame is rendered in a few parts (whole rows), and the readback of a part runs on a
 // second stream while the next part renders; a page-locked pixmap is the target of the DMA itself, any other
 // is filled from page-locked staging memory, the host copy of a part overlapping the transfer of the next.
 // Nothing is allocated per frame: framebuffer and staging grow when a larger frame comes and are kept.
-#define RENDER_PARTS_MAX 8
-#define READBACK_PROBES 8
+#define READBACK_PROBES 6
 #define READBACK_RETRY 32
 extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                             const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats) {
@@ -4513,15 +4556,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         HIP_TRY(hipMalloc((void **)&sc->fb, bytes));
         sc->fb_bytes = bytes;
     }
-    if (!sc->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream, hipStreamNonBlocking));
-    if (!sc->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream2, hipStreamNonBlocking));
-    while (sc->ev_copy.size() < RENDER_PARTS_MAX) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        sc->ev_copy.push_back(e);
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        sc->ev_part.push_back(e);
-    }
+    { int rc0 = ensure_readback(sc); if (rc0) return rc0; }
     const bool pinned = host_is_pinned(pixmap);
     const bool refract = sc->refractive && (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
     const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
@@ -4538,9 +4573,12 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // frame's last stage in four parts, each copied while the next is shaded, beats k_average writing the whole frame
     // across at the end (10 000 spheres 3.44 against 3.67 ms, the 100 000-triangle mesh 1.49 against 1.75).  Which it
     // is the handle finds out by timing its calls on the host: the first READBACK_PROBES frames of a kind (size,
-    // shader, lights) go one way and the other in turn, the frames after them the way whose shortest of its last
-    // three calls was shorter, and every READBACK_RETRY-th frame the other way once more (the first frames of a
-    // process are slow either way, and what the link to the host gives changes while a process runs).  The event the call waits on orders the
+    // shader, lights) go direct, copied, copied, copied, direct, direct -- the first direct write is what makes the
+    // device map the pixmap's pages (copies alone take eight calls to reach their speed: 20, 0.8, 5.8, 0.7 ... 0.53 ms
+    // for the default scene; after one direct frame the second copied frame has it), and two direct frames in a row
+    // show what those cost back to back --, the frames after them go the way whose shortest of its last three calls
+    // was shorter, and every READBACK_RETRY-th frame the other way once more
+    // (what the link to the host gives changes while a process runs).  The event the call waits on orders the
     // writes before the caller's reads.  (RT355_READBACK_COPY / RT355_READBACK_DIRECT force one way.)
     bool direct = pinned, timing = false;
     if (pinned && (one_kernel || tail_way)) {
@@ -4556,7 +4594,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
             return best;
         };
         const bool faster_direct = recent(0) <= recent(1);
-        if (sc->readback_frames < READBACK_PROBES) direct = (sc->readback_frames & 1) == 0;
+        if (sc->readback_frames < READBACK_PROBES) direct = sc->readback_frames == 0 || sc->readback_frames >= READBACK_PROBES - 2;
         else direct = (sc->readback_frames % READBACK_RETRY == 0) ? !faster_direct : faster_direct;
         timing = true;
     }
@@ -4716,16 +4754,9 @@ extern "C" int rt355_render_sweep(rt355_scene *sc, const rt355_camera *cams, int
         HIP_TRY(hipMalloc((void **)&sc->fb2, bytes));
         sc->fb2_bytes = bytes;
     }
-    if (!sc->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->copy_stream, hipStreamNonBlocking));
+    { int rc0 = ensure_readback(sc); if (rc0) return rc0; }
     if (!sc->sweep_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->sweep_stream, hipStreamNonBlocking));
     const hipStream_t st = sc->sweep_stream; // (two handles sweeping from two host threads then overlap on the GPU)
-    while (sc->ev_copy.size() < 2) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        sc->ev_copy.push_back(e);
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        sc->ev_part.push_back(e);
-    }
     bool any_pageable = false;
     for (int i = 0; i < n_frames; i++) any_pageable = any_pageable || !host_is_pinned(pixmaps[i]);
     if (any_pageable && bytes > sc->stage_bytes) {

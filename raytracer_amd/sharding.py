@@ -4,7 +4,10 @@ Three partitions, none with a collective inside the frame:
   * row slabs of one frame (rank r renders rows [r*H/N, (r+1)*H/N)),
   * interleaved row tiles of one frame (tile k of `tile_rows` rows goes to rank k mod N: the partition for
     frames whose cost is uneven from top to bottom -- sky above, geometry below),
-    each followed by ONE gather of the final frame on the destination rank, the only exchange of the path;
+    each followed by the final frame coming together in ONE place, the only exchange of the path: every rank's
+    rt355_render writes its rows over its own GPU's link straight into one pixmap in host memory that the ranks share
+    (SharedPixmap; a barrier tells when the frame is complete), or the rows are gathered on one GPU (gather_frame:
+    over xGMI with RCCL) and read back from there;
   * whole frames of a camera sweep, frame f on rank f mod N (no exchange at all).
 Works on any torch.distributed backend (nccl = RCCL on the GPU box, gloo in CPU tests).
 """
@@ -44,6 +47,56 @@ def rows_of(height: int, world: int, rank: int, shard: str, tile_rows: int = TIL
 def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
     """Round-robin frame assignment of a camera sweep: frame f goes to rank f mod world."""
     return list(range(rank, n_frames, world))
+
+
+class SharedPixmap:
+    """One (height, width, 3) uint8 pixmap in host memory shared by every rank of the job (a file in /dev/shm that
+    all of them map), page-locked by each rank for its own GPU where the runtime allows it: rank r's rt355_render writes r's rows of the frame
+    straight into it, so the frame comes together in the caller's memory over N links at once and nothing passes
+    through another GPU.  `dist` is torch.distributed (initialised); register=False leaves the memory pageable
+    (CPU tests)."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, dist, register: bool = True):
+        import mmap
+        import os
+        import numpy as np
+        n = width * height * 3
+        name = [None]
+        if rank == 0:
+            name[0] = f"/dev/shm/rt355_pixmap_{os.getpid()}_{id(self):x}"
+            with open(name[0], "wb") as f:
+                f.truncate(n)
+        if world > 1:
+            dist.broadcast_object_list(name, src=0)
+        fd = os.open(name[0], os.O_RDWR)
+        try:
+            self._map = mmap.mmap(fd, n)
+        finally:
+            os.close(fd)
+        if world > 1:
+            dist.barrier()  # every rank has mapped it: the name can go
+        if rank == 0:
+            os.unlink(name[0])
+        self.array = np.frombuffer(self._map, dtype=np.uint8).reshape(height, width, 3)
+        # (the HIP runtime of this image refuses to page-lock a mapping that a file backs -- /dev/shm and memfd
+        # alike --: the pixmap then stays pageable, and rt355_render passes a rank's rows through the handle's own
+        # page-locked staging memory, part by part as they arrive)
+        self.registered = False
+        if register:
+            from .api import lib
+            self.registered = lib().rt355_host_register(self.array.ctypes.data, n) == 0
+
+    def close(self):
+        if self.array is not None:
+            if self.registered:
+                from .api import lib
+                lib().rt355_host_unregister(self.array.ctypes.data)
+                self.registered = False
+            self.array = None
+            try:
+                self._map.close()
+            except BufferError:  # (a view of the array is still alive somewhere: the mapping goes with it)
+                pass
 
 
 def gather_frame(local_frame, rank: int, world: int, dst: int = 0, shard: str = "slabs", tile_rows: int = TILE_ROWS):

@@ -17,7 +17,7 @@ def _worker(rank, world, port, out_dir):
     from oracle.oracle_py import Oracle
     from raytracer_amd import binding as B
     from raytracer_amd import scenes as S
-    from raytracer_amd.sharding import frames_for_rank, gather_frame, slab_rows, tile_rows_of
+    from raytracer_amd.sharding import SharedPixmap, frames_for_rank, gather_frame, slab_rows, tile_rows_of
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,6 +33,15 @@ def _worker(rank, world, port, out_dir):
         np.save(os.path.join(out_dir, "slabs.npy"), full.numpy())
     else:
         assert full is None
+    # the same slabs into one pixmap that the ranks share in host memory (pageable here: no GPU): every rank writes its
+    # rows, a barrier, and the frame is whole on every rank
+    shared = SharedPixmap(w, h, rank, world, dist, register=False)
+    O.render(p, cam, sh, B.opts(w, h, row_begin=b, row_end=e), threads=2, out=shared.array)
+    dist.barrier()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "shared.npy"), shared.array.copy())
+    dist.barrier()
+    shared.close()
     # interleaved row tiles of 16 rows: the call renders this rank's share in place, one gather assembles the frame
     local = np.zeros((h, w, 3), dtype=np.uint8)
     O.render(p, cam, sh, B.opts(w, h, tile_rows=16, tile_count=world, tile_phase=rank), threads=2, out=local)
@@ -68,6 +77,7 @@ def test_slabs_and_sweep_world2(tmp_path, oracle):
     got = np.load(tmp_path / "slabs.npy")
     assert np.array_equal(got, want)
     assert np.array_equal(np.load(tmp_path / "tiles.npy"), want)
+    assert np.array_equal(np.load(tmp_path / "shared.npy"), want)
     sweep = np.load(tmp_path / "sweep.npy")
     for f in range(5):
         frame, _ = oracle.render(sc.pack(), S.orbit_camera(f, 48, 32, n_frames=5, center=(0, 0, 0), radius=30, eye_z=8),

@@ -33,9 +33,12 @@ def test_two_ranks_whole_frames():
     assert abs(two["value"] * two["ms_per_step"] * 1e3 - 2 * rays) < 1e-3 * rays
 
 
+@pytest.mark.parametrize("gather", ["host", "xgmi"])
 @pytest.mark.parametrize("shard", ["slabs", "tiles"])
-def test_two_ranks_share_a_frame(shard):
-    d = _bench("--gpus", "2", "--shard", shard, "--workload", "spheres10k_8lights_4k")
+def test_two_ranks_share_a_frame(shard, gather):
+    """gather = host: every rank's rt355_render writes its rows into one page-locked pixmap the ranks share;
+    xgmi: the rows are gathered on rank 0's GPU and read back there."""
+    d = _bench("--gpus", "2", "--shard", shard, "--gather", gather, "--workload", "spheres10k_8lights_4k")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shard"] == shard
     assert d["gathered_frame"] == "ok"
     r = d["config"]["rays_per_frame"]
