@@ -84,6 +84,31 @@ __device__ __forceinline__ void spill_candidate(const Spill &sp, uint32_t rid, u
         head[rid] = at;
     }
 }
+// Candidates appended by SEVERAL waves to one ray's list (the packet search hands the rest of a wave's walk to many
+// waves once the wave has met HEAVY_AFTER primitives, see k_search_packet): the slot comes from the ray's count in
+// memory, and a spilled entry takes the ray's previous chain head in exchange for itself (the head of a ray without
+// a chain has been set to POOL_END by the wave that handed over).
+__device__ __forceinline__ void append_id_shared(uint32_t id, uint32_t rid, uint32_t n_rays, uint32_t *cand,
+                                                 uint32_t *cand_cnt, const Spill &sp) {
+    const uint32_t slot = atomicAdd(&cand_cnt[rid], 1u);
+    if (slot < CAND_CAP) { cand[(size_t)slot * n_rays + rid] = id; return; }
+    const uint32_t at = atomicAdd(sp.count, 1u);
+    if (at < POOL_CAP) {
+        const uint32_t prev = atomicExch(&spill_head(sp)[rid], at);
+        sp.pool[at] = make_uint2(id, prev);
+    }
+}
+// The waves of a packet search that handed the rest of their walk over: (workgroup << 2 | wave, ordinal of the first
+// surviving chunk left), per workspace slot, and how many there are.
+#ifndef HEAVY_CAP
+#define HEAVY_CAP 8192u     // entries per slot; a wave that finds the list full walks on by itself
+#endif
+#define HEAVY_MIN_PRIMS 300000 // scenes below this are searched in one launch (the second costs 0.02 ms and gains nothing there)
+#define HEAVY_WORKERS 32u   // waves that share what one such wave left
+#ifndef HEAVY_AFTER
+#define HEAVY_AFTER 1024u   // primitives met (64 pair tests each) after which a wave hands over
+#endif
+struct Heavy { uint2 *list; uint32_t *count; uint32_t after; }; // after: HEAVY_AFTER (tests lower it)
 #define CAND_SPHERE 0x40000000u
 #define CAND_TRI 0x80000000u
 #define CAND_ENVIRONMENT (CAND_SPHERE | CAND_TRI) // both bits: an Environment (its record is a sphere's)
@@ -182,6 +207,7 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *cand_cnt;   // [n] candidates found
     uint32_t *cand;       // [CAND_CAP][n]
     Spill spill;          // [POOL_CAP] spilled candidates and [1] their count, per slot
+    Heavy heavy;          // [HEAVY_CAP] waves of a packet search that handed their walk over and [1] their count, per slot
     uint32_t *tile_count; // [tile_stride] active rays per tile, then exclusive offsets; entry [tiles] = total
     uint32_t *active_rid; // [list_stride] rids of the slot's active rays, tile-major or direction-sorted
     uint32_t *bin_hist;   // [HIST_STRIDE] packet search: rays per (direction bin, counter shard), then offsets
@@ -922,6 +948,23 @@ __device__ __forceinline__ float pair_margin(float x, float y, float z, const fl
     return __builtin_fmaf(-dv, dv, __builtin_fmaf(-du, du, p.z));
 }
 
+// the rows of a triangle: is the ray's direction inside the pyramid over it / its projected origin inside the projected triangle?
+template <int KIND>
+__device__ __forceinline__ bool rows_pass(const float4 &a, const float4 &b, const float4 &c, float x, float y, float z, float lin) {
+    float ea, eb, ec, floor_;
+    if (KIND == 1) {
+        ea = __builtin_fmaf(z, a.z, __builtin_fmaf(y, a.y, x * a.x));
+        eb = __builtin_fmaf(z, b.z, __builtin_fmaf(y, b.y, x * b.x));
+        ec = __builtin_fmaf(z, c.z, __builtin_fmaf(y, c.y, x * c.x));
+        floor_ = -1e-6f;
+    } else {
+        ea = __builtin_fmaf(y, a.y, __builtin_fmaf(x, a.x, a.z));
+        eb = __builtin_fmaf(y, b.y, __builtin_fmaf(x, b.x, b.z));
+        ec = __builtin_fmaf(y, c.y, __builtin_fmaf(x, c.x, c.z));
+        floor_ = -lin;
+    }
+    return fminf(ea, fminf(eb, ec)) >= floor_;
+}
 template <int KIND>
 __device__ __forceinline__ void append_rows(const float4 &a, const float4 &b, const float4 &c, float x, float y,
                                             float z, float lin, uint32_t rid, uint32_t n_rays, uint32_t *cand,
@@ -1089,26 +1132,48 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-template <int KIND, int PR>
-__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
+// HEAVY: the second launch of a search.  A wave whose beam grazes a finely tessellated surface meets thousands of
+// primitives where the others meet ten, and a launch lasts as long as its longest wave (the 100 000-triangle frame:
+// 7.5 primitives a wave on average, 3 152 in the worst; a million triangles at 7680x4320: 38 and 25 800).  A wave of
+// the first launch that has met HEAVY_AFTER primitives therefore stops at the next chunk, leaves its rays' counts as
+// they are and puts itself on a list; in the second launch HEAVY_WORKERS waves per entry take the same rays, walk the
+// same bounds (the walk is deterministic: surviving chunks are counted as they come) and share the chunks from
+// where the first wave stopped, appending through append_id_shared.
+// MODE 0: one launch, no wave hands over (scenes below HEAVY_MIN_PRIMS run the kernel they always ran); 1: the first
+// launch of two; 2: the second.
+template <int KIND, int PR, int MODE>
+__device__ __forceinline__ void packet_search_wave(uint32_t block_x, const Tables &t_all,
                                                                   const float4 *__restrict__ ray32_all, uint32_t n_rays,
                                                                   const uint32_t *__restrict__ active_rid_all,
                                                                   const uint32_t *__restrict__ n_active_all,
                                                                   uint32_t *__restrict__ cand_all,
                                                                   uint32_t *__restrict__ cand_cnt_all,
                                                                   unsigned long long *__restrict__ counters, Spill sp_all,
-                                                                  Slots sl, uint32_t list_stride, uint32_t n_active_stride) {
+                                                                  const Slots &sl, uint32_t list_stride, uint32_t n_active_stride,
+                                                                  const Heavy &hv_all) {
     // the slot of this launch row: its tables, rays, list and candidate arrays
     const size_t g = (size_t)sl.slot[blockIdx.y];
     const Tables tb = slot_tables(t_all, (size_t)sl.table[blockIdx.y]);
+    constexpr bool HEAVY = MODE == 2;
+    uint2 *__restrict__ hv_list = MODE ? hv_all.list + g * HEAVY_CAP : nullptr;
+    uint32_t *__restrict__ hv_count = MODE ? hv_all.count + g : nullptr;
     const float4 *__restrict__ ray32 = ray32_all + g * n_rays;
     const uint32_t *__restrict__ active_rid = active_rid_all ? active_rid_all + g * list_stride : nullptr;
     const uint32_t *__restrict__ n_active = active_rid_all ? n_active_all + g * n_active_stride : nullptr;
     uint32_t *__restrict__ cand = cand_all + g * CAND_CAP * n_rays, *__restrict__ cand_cnt = cand_cnt_all + g * n_rays;
     Spill sp; sp.pool = sp_all.pool + g * POOL_STRIDE(n_rays); sp.count = sp_all.count + g;
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t t = threadIdx.x, lane = t & 63u;
     const uint32_t total = active_rid ? *n_active : n_rays;
-    if (blockIdx.x * (PACKET_THREADS * PR) >= total) return;
+    // the wave whose rays these are: this one, or (HEAVY) the wave of the first launch that this one helps
+    uint32_t bx = block_x, wave = t >> 6, worker = 0, k_stop = 0;
+    if (HEAVY) {
+        const uint32_t entry = block_x / (HEAVY_WORKERS / PACKET_WAVES);
+        if (entry >= min(*hv_count, HEAVY_CAP)) return;
+        const uint2 he = hv_list[entry];
+        worker = (block_x % (HEAVY_WORKERS / PACKET_WAVES)) * PACKET_WAVES + wave;
+        bx = he.x >> 2; wave = he.x & 3u; k_stop = he.y;
+    }
+    if (bx * (PACKET_THREADS * PR) >= total) return;
     float rx[PR], ry[PR], rz[PR], rw[PR];
     uint32_t cnt[PR], rid[PR];
     bool live[PR];
@@ -1117,12 +1182,12 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     for (int r = 0; r < PR; r++) {
         uint32_t slot;
         if (active_rid) { // sorted list: a wave takes 64*PR consecutive entries
-            slot = blockIdx.x * (PACKET_THREADS * PR) + wave * (64 * PR) + r * 64 + lane;
+            slot = bx * (PACKET_THREADS * PR) + wave * (64 * PR) + r * 64 + lane;
         } else {
             // camera rays: ray r of the wave's lanes = one 8x8 pixel block (4x4 quads of a quarter tile, 16
             // lanes per quad pixel, so a load touches 64-byte runs); 16 blocks per tile, a wave takes
             // PR consecutive ones
-            const uint32_t blk = (blockIdx.x * PACKET_WAVES + wave) * PR + (uint32_t)r;
+            const uint32_t blk = (bx * PACKET_WAVES + wave) * PR + (uint32_t)r;
             const uint32_t tile = blk / 16u, quarter = (blk / 4u) % 4u, qb = blk % 4u;
             const uint32_t qi = lane & 15u, pix = lane >> 4;
             const uint32_t quad = ((qb & 1u) * 4u + (qi & 3u)) + 8u * ((qb >> 1) * 4u + (qi >> 2));
@@ -1143,7 +1208,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     msq_max = wave_max_f(msq_max);
     if (!(nact > 0.f)) { // nothing to search for in this wave (uniform)
 #pragma unroll
-        for (int r = 0; r < PR; r++) if (live[r]) cand_cnt[rid[r]] = 0;
+        for (int r = 0; r < PR; r++) if (live[r] && !HEAVY) cand_cnt[rid[r]] = 0;
         return;
     }
     float wx, wy, wz = 0.f, w_cos = -1.f, w_sin = 0.f, w_rho = 0.f;
@@ -1192,6 +1257,8 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
     };
 
     uint32_t n_surv = 0;
+    uint32_t k_ord = 0;         // surviving chunks so far, in the order of the walk
+    bool may_hand_over = MODE == 1 && bx < (1u << 30);
 #ifdef RT355_DEBUG_SURVIVORS
     uint32_t dbg_super = 0, dbg_chunk = 0;
 #endif
@@ -1221,6 +1288,60 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
 #ifdef RT355_DEBUG_SURVIVORS
             dbg_chunk += (uint32_t)__popcll(m_chunk);
 #endif
+            // one primitive of a chunk (lane i's records) against the rays of every lane
+            auto test_primitive = [&](int i, const float4 &p, const float4 &ra, const float4 &rb, const float4 &rc) {
+                float4 q;
+                q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
+                bool hit[PR];
+                bool any_hit = false;
+#pragma unroll
+                for (int r = 0; r < PR; r++) {
+                    hit[r] = pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f);
+                    any_hit |= hit[r];
+                }
+                if (!any_hit) return;
+                // some ray is inside the cone / circle; triangles also have pyramid / edge-function rows
+                const uint32_t id = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(ra.w), i); // the candidate id
+                if (id & CAND_TRI) {
+                    float4 ea, eb, ec;
+                    ea.x = lane_bcast(ra.x, i); ea.y = lane_bcast(ra.y, i); ea.z = lane_bcast(ra.z, i);
+                    ea.w = __uint_as_float(id);
+                    eb.x = lane_bcast(rb.x, i); eb.y = lane_bcast(rb.y, i); eb.z = lane_bcast(rb.z, i); eb.w = 0.f;
+                    ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
+#pragma unroll
+                    for (int r = 0; r < PR; r++) {
+                        if (!hit[r]) continue;
+                        if (!HEAVY) append_rows<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r], sp);
+                        else if (rows_pass<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r])) append_id_shared(id, rid[r], n_rays, cand, cand_cnt, sp);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < PR; r++) {
+                        if (!hit[r]) continue;
+                        if (!HEAVY) append_id(id, rid[r], n_rays, cand, cnt[r], sp);
+                        else append_id_shared(id, rid[r], n_rays, cand, cand_cnt, sp);
+                    }
+                }
+            };
+            if (HEAVY) { // this wave's share of the chunks the first wave left: no rows in flight, a chunk at a time
+                while (m_chunk) {
+                    const int c = __builtin_ctzll(m_chunk);
+                    m_chunk &= m_chunk - 1ull;
+                    const uint32_t ord = k_ord++;
+                    if (ord < k_stop || (ord - k_stop) % HEAVY_WORKERS != worker) continue;
+                    const size_t at = ((size_t)sc * 64 + c) * 64 + lane;
+                    const float4 p = tb.L1[at], ra = tb.L2[3 * at], rb = tb.L2[3 * at + 1], rc = tb.L2[3 * at + 2];
+                    const float st = (KIND == 1) ? tb.L1s[at] : 0.f;
+                    unsigned long long mask = __ballot(meets(p, st));
+                    n_surv += (uint32_t)__popcll(mask);
+                    while (mask) {
+                        const int i = __builtin_ctzll(mask);
+                        mask &= mask - 1ull;
+                        test_primitive(i, p, ra, rb, rc);
+                    }
+                }
+                continue;
+            }
             float4 np, na, nb, nc; float nst = 0.f; // rows of the next surviving chunk, in flight
             auto fetch_chunk = [&](int c) {
                 const size_t at = ((size_t)sc * 64 + c) * 64 + lane;
@@ -1234,47 +1355,45 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
                 const float4 p = np, ra = na, rb = nb, rc = nc;
                 const float st = nst;
                 if (m_chunk) { c_next = __builtin_ctzll(m_chunk); fetch_chunk(c_next); }
+                k_ord++;
                 // ---- the 64 primitives of the chunk
                 unsigned long long mask = __ballot(meets(p, st));
                 n_surv += (uint32_t)__popcll(mask);
                 while (mask) {
                     const int i = __builtin_ctzll(mask);
                     mask &= mask - 1ull;
-                    float4 q;
-                    q.x = lane_bcast(p.x, i); q.y = lane_bcast(p.y, i); q.z = lane_bcast(p.z, i); q.w = lane_bcast(p.w, i);
-                    bool hit[PR];
-                    bool any_hit = false;
-#pragma unroll
-                    for (int r = 0; r < PR; r++) {
-                        hit[r] = pair_margin<KIND>(rx[r], ry[r], rz[r], q) >= (KIND == 2 ? -rz[r] : 0.0f);
-                        any_hit |= hit[r];
-                    }
-                    if (!any_hit) continue;
-                    // some ray is inside the cone / circle; triangles also have pyramid / edge-function rows
-                    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(ra.w), i); // the candidate id
-                    if (id & CAND_TRI) {
-                        float4 ea, eb, ec;
-                        ea.x = lane_bcast(ra.x, i); ea.y = lane_bcast(ra.y, i); ea.z = lane_bcast(ra.z, i);
-                        ea.w = __uint_as_float(id);
-                        eb.x = lane_bcast(rb.x, i); eb.y = lane_bcast(rb.y, i); eb.z = lane_bcast(rb.z, i); eb.w = 0.f;
-                        ec.x = lane_bcast(rc.x, i); ec.y = lane_bcast(rc.y, i); ec.z = lane_bcast(rc.z, i); ec.w = 0.f;
+                    test_primitive(i, p, ra, rb, rc);
+                }
+                // ---- met enough for one wave: the rest of the walk goes to the second launch (uniform)
+                if (MODE == 1 && n_surv >= hv_all.after && may_hand_over && (m_chunk || m_super || (top + 1) * 64 < n_super)) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(hv_count, 1u);
+                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                    if (at < HEAVY_CAP) {
+                        if (lane == 0) hv_list[at] = make_uint2((bx << 2) | wave, k_ord);
 #pragma unroll
                         for (int r = 0; r < PR; r++)
-                            if (hit[r]) append_rows<KIND>(ea, eb, ec, rx[r], ry[r], rz[r], rw[r], rid[r], n_rays, cand, cnt[r], sp);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < PR; r++)
-                            if (hit[r]) append_id(id, rid[r], n_rays, cand, cnt[r], sp);
+                            if (live[r]) {
+                                cand_cnt[rid[r]] = cnt[r];
+                                if (cnt[r] <= CAND_CAP) spill_head(sp)[rid[r]] = POOL_END; // no chain yet: the helpers start one
+                            }
+                        if (lane == 0) atomicAdd(&counters[(bx % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
+                        return;
                     }
+                    may_hand_over = false; // the list is full: this wave walks on by itself
                 }
             }
         }
+    }
+    if (HEAVY) {
+        if (lane == 0 && n_surv) atomicAdd(&counters[(block_x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
+        return;
     }
 #pragma unroll
     for (int r = 0; r < PR; r++)
         if (live[r]) cand_cnt[rid[r]] = cnt[r];
     if (lane == 0 && n_surv) {
-        atomicAdd(&counters[(blockIdx.x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
+        atomicAdd(&counters[(block_x % COUNTER_SHARDS) * COUNTER_STRIDE + 3], (unsigned long long)n_surv);
     }
 #ifdef RT355_DEBUG_SURVIVORS
     if (lane == 0) {
@@ -1284,6 +1403,29 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all,
         atomicAdd(&counters[11], (unsigned long long)dbg_chunk);
     }
 #endif
+}
+// The first launch: a workgroup per PACKET_WAVES waves of rays.  The second (HEAVY): a fixed grid whose workgroups
+// take the helpers' places in turn, HEAVY_WORKERS / PACKET_WAVES of them per entry of the list.
+#ifndef HEAVY_GRID
+#define HEAVY_GRID 2048u
+#endif
+template <int KIND, int PR, int MODE>
+__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all, const float4 *__restrict__ ray32_all, uint32_t n_rays,
+                                                                  const uint32_t *__restrict__ active_rid_all,
+                                                                  const uint32_t *__restrict__ n_active_all,
+                                                                  uint32_t *__restrict__ cand_all, uint32_t *__restrict__ cand_cnt_all,
+                                                                  unsigned long long *__restrict__ counters, Spill sp_all,
+                                                                  Slots sl, uint32_t list_stride, uint32_t n_active_stride,
+                                                                  Heavy hv_all) {
+    if (MODE != 2) {
+        packet_search_wave<KIND, PR, MODE>(blockIdx.x, t_all, ray32_all, n_rays, active_rid_all, n_active_all, cand_all, cand_cnt_all,
+                                            counters, sp_all, sl, list_stride, n_active_stride, hv_all);
+        return;
+    }
+    const uint32_t places = min(hv_all.count[sl.slot[blockIdx.y]], HEAVY_CAP) * (HEAVY_WORKERS / PACKET_WAVES);
+    for (uint32_t b = blockIdx.x; b < places; b += gridDim.x)
+        packet_search_wave<KIND, PR, 2>(b, t_all, ray32_all, n_rays, active_rid_all, n_active_all, cand_all, cand_cnt_all,
+                                           counters, sp_all, sl, list_stride, n_active_stride, hv_all);
 }
 
 // ---- search for rays that share neither origin nor direction (mirror rays) -----------------------------
@@ -3658,6 +3800,7 @@ static void free_tables(rt355_scene *sc) {
 static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
+                  w.heavy.list, w.heavy.count,
                   w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d,
                   w.g_live};
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -3767,6 +3910,8 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.cand_cnt, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.spill.pool, g * POOL_STRIDE(n) * sizeof(uint2)));
     HIP_TRY(hipMalloc((void **)&w.spill.count, LIGHT_GROUP * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.heavy.list, (size_t)LIGHT_GROUP * HEAVY_CAP * sizeof(uint2)));
+    HIP_TRY(hipMalloc((void **)&w.heavy.count, LIGHT_GROUP * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.cand, g * CAND_CAP * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.tile_count, g * (n / RAYS_PER_TILE + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.active_rid, g * (n + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX) * sizeof(uint32_t)));
@@ -4047,6 +4192,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         return sc->tune_ms[cls][0] <= sc->tune_ms[cls][1] ? 4 : 1;
     };
     // one search launch over the given slots (all of bundle kind `kind`); list / total = null for the camera rays
+    const int heavy_min_prims = getenv("RT355_HEAVY_MIN_PRIMS") ? atoi(getenv("RT355_HEAVY_MIN_PRIMS")) : HEAVY_MIN_PRIMS; // (tests: 0 = always)
     auto launch_search = [&](int kind, const Slots &sl, const uint32_t *list, const uint32_t *total,
                              uint32_t total_stride) -> int {
         for (int i = 0; i < sl.count; i++) // empty spill lists for the bundles of this launch
@@ -4057,7 +4203,17 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             sc->launch_choice.push_back({cls, pr});
             const size_t n_entries = list ? (size_t)w.list_stride : (size_t)f.n_rays, per_block = (size_t)PACKET_THREADS * pr;
             const dim3 grid((unsigned)((n_entries + per_block - 1) / per_block), (unsigned)sl.count);
-#define LAUNCH_PACKET(K, P) hipLaunchKernelGGL((k_search_packet<K, P>), grid, dim3(PACKET_THREADS), 0, st, sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride)
+            // the search, then the waves that share what its longest waves handed over (blocks past the list's end leave at once)
+            const dim3 grid_heavy(HEAVY_GRID, (unsigned)sl.count);
+            const bool two_launches = sc->view.n_prims >= heavy_min_prims;
+            Heavy hv = w.heavy;
+            hv.after = getenv("RT355_HEAVY_AFTER") ? (uint32_t)atoi(getenv("RT355_HEAVY_AFTER")) : HEAVY_AFTER; // (tests: hand over early)
+            if (two_launches) HIP_TRY(hipMemsetAsync(w.heavy.count, 0, LIGHT_GROUP * sizeof(uint32_t), st));
+#define PACKET_ARGS sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride, hv
+#define LAUNCH_PACKET(K, P) do { \
+    if (!two_launches) hipLaunchKernelGGL((k_search_packet<K, P, 0>), grid, dim3(PACKET_THREADS), 0, st, PACKET_ARGS); \
+    else { hipLaunchKernelGGL((k_search_packet<K, P, 1>), grid, dim3(PACKET_THREADS), 0, st, PACKET_ARGS); \
+           hipLaunchKernelGGL((k_search_packet<K, P, 2>), grid_heavy, dim3(PACKET_THREADS), 0, st, PACKET_ARGS); } } while (0)
             if (kind == 1 && pr == 4) LAUNCH_PACKET(1, 4);
             else if (kind == 1) LAUNCH_PACKET(1, 1);
             else if (pr == 4) LAUNCH_PACKET(2, 4);

@@ -186,6 +186,38 @@ def test_sweep_entry_point(api):
         r.close()
 
 
+def test_search_in_two_launches(api, oracle, monkeypatch):
+    """The packet search of a large scene runs as two launches: a wave that has met enough primitives hands the rest
+    of its walk to many waves, which append to its rays' lists through the rays' counts in memory.  Forced here on
+    small scenes, with waves handing over after 4 and after 64 primitives (and a list of candidates that overflows
+    into the spill chains): frames, ray counts and the candidates evaluated equal the one-launch search's, the
+    all-pairs search's and the checker's."""
+    cases = [("spheres300", {}), ("mesh", {}), ("mirrors_mesh", {})]
+    sc_big = S.mesh_scene(6000, seed=7, tex_size=64)
+    for name, _ in cases + [("mesh6k", {})]:
+        if name == "mesh6k":
+            sc, sh, (w, h) = sc_big, S.mesh_shader(), (224, 128)
+            cam = S.default_camera(w, h)
+        else:
+            sc, sh, cam, w, h = S.small_case(name)
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
+        r = api.Renderer(sc)
+        one, ost = r.render(cam, sh, w, h)
+        allp, ast = r.render(cam, sh, w, h, mode=B.MODE_ALLPAIRS)
+        assert np.array_equal(one, want) and np.array_equal(allp, want)
+        for after in ("4", "64"):
+            monkeypatch.setenv("RT355_HEAVY_MIN_PRIMS", "0")
+            monkeypatch.setenv("RT355_HEAVY_AFTER", after)
+            two, tst = r.render(cam, sh, w, h)
+            monkeypatch.delenv("RT355_HEAVY_MIN_PRIMS")
+            monkeypatch.delenv("RT355_HEAVY_AFTER")
+            assert np.array_equal(two, want), (name, after)
+            for k in ("shadow_rays", "exact_tests", "overflow_rays", "secondary_rays"):
+                assert tst[k] == ost[k] == ast[k], (name, after, k)
+            assert tst["shadow_rays"] == wst["shadow_rays"]
+        r.close()
+
+
 def test_searched_gather_without_lights(api, oracle):
     """The gather shaders use no lights (main.cpp:205: shading3 takes none), so an empty light list is a natural
     call; on a searched scene the frame then records its two search launches with no light group at all."""
