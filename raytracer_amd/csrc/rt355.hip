@@ -104,9 +104,11 @@ __device__ __forceinline__ void append_id_shared(uint32_t id, uint32_t rid, uint
 #define HEAVY_CAP 8192u     // entries per slot; a wave that finds the list full walks on by itself
 #endif
 #define HEAVY_MIN_PRIMS 300000 // scenes below this are searched in one launch (the second costs 0.02 ms and gains nothing there)
-#define HEAVY_WORKERS 32u   // waves that share what one such wave left
+#ifndef HEAVY_WORKERS
+#define HEAVY_WORKERS 16u   // waves that share what one such wave left
+#endif
 #ifndef HEAVY_AFTER
-#define HEAVY_AFTER 1024u   // primitives met (64 pair tests each) after which a wave hands over
+#define HEAVY_AFTER 768u    // primitives met (64 pair tests each) after which a wave hands over
 #endif
 struct Heavy { uint2 *list; uint32_t *count; uint32_t after; }; // after: HEAVY_AFTER (tests lower it)
 #define CAND_SPHERE 0x40000000u
@@ -1135,7 +1137,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 // HEAVY: the second launch of a search.  A wave whose beam grazes a finely tessellated surface meets thousands of
 // primitives where the others meet ten, and a launch lasts as long as its longest wave (the 100 000-triangle frame:
 // 7.5 primitives a wave on average, 3 152 in the worst; a million triangles at 7680x4320: 38 and 25 800).  A wave of
-// the first launch that has met HEAVY_AFTER primitives therefore stops at the next chunk, leaves its rays' counts as
+// the first launch that has met HEAVY_AFTER (768) primitives therefore stops at the next chunk, leaves its rays' counts as
 // they are and puts itself on a list; in the second launch HEAVY_WORKERS waves per entry take the same rays, walk the
 // same bounds (the walk is deterministic: surviving chunks are counted as they come) and share the chunks from
 // where the first wave stopped, appending through append_id_shared.
