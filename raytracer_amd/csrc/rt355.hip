@@ -4196,8 +4196,8 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     // one search launch over the given slots (all of bundle kind `kind`); list / total = null for the camera rays
     const int heavy_min_prims = getenv("RT355_HEAVY_MIN_PRIMS") ? atoi(getenv("RT355_HEAVY_MIN_PRIMS")) : HEAVY_MIN_PRIMS; // (tests: 0 = always)
     auto launch_search = [&](int kind, const Slots &sl, const uint32_t *list, const uint32_t *total,
-                             uint32_t total_stride) -> int {
-        for (int i = 0; i < sl.count; i++) // empty spill lists for the bundles of this launch
+                             uint32_t total_stride, bool spill_cleared = false) -> int {
+        for (int i = 0; i < sl.count && !spill_cleared; i++) // empty spill lists for the bundles of this launch
             HIP_TRY(hipMemsetAsync(w.spill.count + sl.slot[i], 0, sizeof(uint32_t), st));
         HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
@@ -4283,9 +4283,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, (unsigned)searched.count), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, searched);
             total = w.tile_count + n_tiles; total_stride = w.tile_stride;
         }
+        // (the spill lists of all the group's bundles emptied by one command, not one each)
+        HIP_TRY(hipMemsetAsync(w.spill.count, 0, LIGHT_GROUP * sizeof(uint32_t), st));
         for (int kind = 1; kind <= 2; kind++)
             if (of_kind[kind].count) {
-                int rc2 = launch_search(kind, of_kind[kind], w.active_rid, total, total_stride);
+                int rc2 = launch_search(kind, of_kind[kind], w.active_rid, total, total_stride, true);
                 if (rc2) return rc2;
             }
         return RT355_OK;
