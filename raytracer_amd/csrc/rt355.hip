@@ -754,57 +754,48 @@ __global__ __launch_bounds__(1024) void k_scan_bins(uint32_t *__restrict__ hist_
     const size_t g = (size_t)sl.slot[blockIdx.x];
     uint32_t *__restrict__ hist = hist_all + g * HIST_STRIDE;
     uint32_t *__restrict__ active_rid = active_rid_all + g * list_stride;
-    // Patch p's counters are RT_PATCH * RT_SHARDS contiguous words.  Wave v owns patches 64 v .. 64 v + 63 and
-    // reads each with one coalesced load (PER words per lane): first for the patch sums, then, after the
-    // scan of the padded sums over the workgroup, again to turn the counters into offsets.
-    __shared__ uint32_t part[1024];
+    // Patch p's counters are RT_PATCH * RT_SHARDS contiguous words, and thread p owns them: they stay in its registers
+    // from the patch's sum, through the scan of the padded sums over the workgroup (shuffles inside a wave, the 16
+    // wave sums through LDS), to the offsets written back in their place.
+    constexpr int WORDS = RT_PATCH * RT_SHARDS;
+    static_assert(WORDS % 2 == 0 && (HIST_STRIDE % 2) == 0, "a patch is read as 8-byte words");
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t pad_from[1024], pad_to[1024];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    constexpr int PER = RT_PATCH * RT_SHARDS / 64; // words of a patch per lane
-    static_assert(RT_PATCH * RT_SHARDS % 64 == 0 && PER >= 1, "a patch must fill whole wave loads");
-#pragma unroll 4
-    for (int i = 0; i < 64; i++) {
-        const uint32_t *src = hist + ((size_t)(wave * 64 + i) * 64 + lane) * PER;
-        uint32_t sum = 0;
+    uint2 *__restrict__ mine = (uint2 *)(hist + (size_t)t * WORDS);
+    uint2 v[WORDS / 2];
+    uint32_t sum_c = 0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) sum += src[k];
+    for (int k = 0; k < WORDS / 2; k++) v[k] = mine[k];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        if (lane == 0) part[wave * 64 + i] = sum;
-    }
-    __syncthreads();
-    const uint32_t sum_c = part[t];
+    for (int k = 0; k < WORDS / 2; k++) sum_c += v[k].x + v[k].y;
     const uint32_t padded = (sum_c + (64u * PACKET_RAYS_MAX - 1u)) / (64u * PACKET_RAYS_MAX) * (64u * PACKET_RAYS_MAX);
-    __syncthreads();
-    part[t] = padded;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t x = (t >= off) ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
+    uint32_t incl = padded; // inclusive scan of the padded sums
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += x;
     }
-    const uint32_t start_c = part[t] - padded; // patch t starts here
-    for (uint32_t i = start_c + sum_c; i < start_c + padded; i++) active_rid[i] = 0xffffffffu; // padding = no ray
-    const uint32_t total = part[1023];
+    if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    part[t] = start_c;
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const uint32_t ws = wave_sum[k]; total += ws; if (k < wave) before += ws; }
+    const uint32_t start_c = before + incl - padded; // patch t starts here
+    // padding = no ray: up to 255 entries behind every patch, written by the waves together (a wave takes every 16th
+    // patch, its lanes neighbouring entries)
+    pad_from[t] = start_c + sum_c; pad_to[t] = start_c + padded;
     __syncthreads();
-#pragma unroll 4
-    for (int i = 0; i < 64; i++) {
-        uint32_t *dst = hist + ((size_t)(wave * 64 + i) * 64 + lane) * PER;
-        uint32_t v[PER], mine = 0;
+    for (int p = wave; p < 1024; p += 16)
+        for (uint32_t i = pad_from[p] + (uint32_t)lane; i < pad_to[p]; i += 64u) active_rid[i] = 0xffffffffu;
+    uint32_t run = start_c;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { v[k] = dst[k]; mine += v[k]; }
-        uint32_t incl = mine; // inclusive scan of the lanes' sums
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t x = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += x;
-        }
-        uint32_t run = part[wave * 64 + i] + incl - mine;
-#pragma unroll
-        for (int k = 0; k < PER; k++) { const uint32_t cnt = v[k]; dst[k] = run; run += cnt; }
+    for (int k = 0; k < WORDS / 2; k++) {
+        uint32_t c = v[k].x; v[k].x = run; run += c;
+        c = v[k].y; v[k].y = run; run += c;
     }
+#pragma unroll
+    for (int k = 0; k < WORDS / 2; k++) mine[k] = v[k];
     if (t == 1023) hist[HIST_TOTAL] = total;
 }
 
