@@ -620,7 +620,19 @@ def spawn_ranks(n: int) -> int:
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
-    codes = [p.wait() for p in procs]
+    # a rank that fails takes the others with it (they would wait for it in the next collective for ever)
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.05)
     return max(abs(c) for c in codes)
 
 

@@ -4,6 +4,7 @@ the barrier / max-over-ranks timing / whole-job ray counts, and for a frame shar
 whose result the benchmark compares with the frame one rank renders alone."""
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -15,11 +16,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _bench(*args):
     env = dict(os.environ, RT355_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "3", "--warmup", "2"],
-                       env=env, capture_output=True, text=True, timeout=280)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE line
+    # (a session of its own: should it hang, the launcher AND its ranks are killed, not the launcher alone)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "3", "--warmup", "2"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        pytest.fail("bench.py " + " ".join(args) + " did not end in 240 s:\n" + err[-2000:])
+    assert p.returncode == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]  # rank 0 prints ONE line
     return json.loads(lines[0])
 
 
