@@ -47,7 +47,7 @@ def _device_frame(api, r, cam, sh, o, w, h):
 
 @pytest.mark.parametrize("name,stride", [("spheres10k_8lights_4k", 16), ("mesh100k_2lights_4k", 16)])
 def test_throughput_scene_at_full_size(api, oracle, name, stride):
-    """BASELINE configs 3 and 4 (one GPU, 3840x2160): every 16th pixel in x and y against the checker, then the
+    """The 10 000-sphere and the 100 000-triangle benchmark frames (one GPU, 3840x2160): every 16th pixel in x and y against the checker, then the
     whole frame against itself through the other search, the two partitions and the other entry point."""
     scene, sh, cam, w, h = bench.build_workload(name)
     packed = scene.pack()
@@ -83,7 +83,7 @@ def test_throughput_scene_at_full_size(api, oracle, name, stride):
 
 
 def test_million_triangles_at_8k(api, oracle):
-    """BASELINE config 4 at its full size: 1 000 000 triangles at 7680x4320.  Every 64th pixel in x and y
+    """The largest benchmark frame at its full size: 1 000 000 triangles at 7680x4320.  Every 64th pixel in x and y
     against the checker (8 160 camera rays and their shadow rays against a million triangles each), eight shares
     of interleaved row tiles against the frame rendered at once."""
     scene, sh, cam, w, h = bench.build_workload("mesh1m_8k_tiles")
@@ -103,7 +103,7 @@ def test_million_triangles_at_8k(api, oracle):
 
 
 def test_camera_sweep_of_the_triangle_scene(api, oracle):
-    """BASELINE config 5: frames of the 60-camera sweep of the 100 000-triangle scene at 3840x2160, one scene
+    """The camera-sweep benchmark: frames of the 60-camera sweep of the 100 000-triangle scene at 3840x2160, one scene
     handle rendering them one after the other (the eye's tables are rebuilt for every frame, the lights' are
     kept): every 32nd pixel of five of them against the checker, and the round-robin deal covers every frame."""
     from raytracer_amd.sharding import frames_for_rank
