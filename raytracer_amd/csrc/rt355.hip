@@ -101,16 +101,16 @@ __device__ __forceinline__ void append_id_shared(uint32_t id, uint32_t rid, uint
 // The waves of a packet search that handed the rest of their walk over: (workgroup << 2 | wave, ordinal of the first
 // surviving chunk left), per workspace slot, and how many there are.
 #ifndef HEAVY_CAP
-#define HEAVY_CAP 8192u     // entries per slot; a wave that finds the list full walks on by itself
+#define HEAVY_CAP 32768u    // entries per slot; a wave that finds the list full walks on by itself
 #endif
 #define HEAVY_MIN_PRIMS 300000 // scenes below this are searched in one launch (the second costs 0.02 ms and gains nothing there)
 #ifndef HEAVY_WORKERS
 #define HEAVY_WORKERS 16u   // waves that share what one such wave left
 #endif
 #ifndef HEAVY_AFTER
-#define HEAVY_AFTER 768u    // primitives met (64 pair tests each) after which a wave hands over
+#define HEAVY_AFTER 256u    // primitives met (64 pair tests each) after which a wave hands over
 #endif
-struct Heavy { uint2 *list; uint32_t *count; uint32_t after; }; // after: HEAVY_AFTER (tests lower it)
+struct Heavy { uint2 *list; uint32_t *count; uint32_t after, workers; }; // after: HEAVY_AFTER, workers: HEAVY_WORKERS (a multiple of PACKET_WAVES), or what the launch's size asks for
 #define CAND_SPHERE 0x40000000u
 #define CAND_TRI 0x80000000u
 #define CAND_ENVIRONMENT (CAND_SPHERE | CAND_TRI) // both bits: an Environment (its record is a sphere's)
@@ -1128,7 +1128,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 // HEAVY: the second launch of a search.  A wave whose beam grazes a finely tessellated surface meets thousands of
 // primitives where the others meet ten, and a launch lasts as long as its longest wave (the 100 000-triangle frame:
 // 7.5 primitives a wave on average, 3 152 in the worst; a million triangles at 7680x4320: 38 and 25 800).  A wave of
-// the first launch that has met HEAVY_AFTER (768) primitives therefore stops at the next chunk, leaves its rays' counts as
+// the first launch that has met HEAVY_AFTER (256) primitives therefore stops at the next chunk, leaves its rays' counts as
 // they are and puts itself on a list; in the second launch HEAVY_WORKERS waves per entry take the same rays, walk the
 // same bounds (the walk is deterministic: surviving chunks are counted as they come) and share the chunks from
 // where the first wave stopped, appending through append_id_shared.
@@ -1160,10 +1160,10 @@ __device__ __forceinline__ void packet_search_wave(uint32_t block_x, const Table
     // the wave whose rays these are: this one, or (HEAVY) the wave of the first launch that this one helps
     uint32_t bx = block_x, wave = t >> 6, worker = 0, k_stop = 0;
     if (HEAVY) {
-        const uint32_t entry = block_x / (HEAVY_WORKERS / PACKET_WAVES);
+        const uint32_t entry = block_x / (hv_all.workers / PACKET_WAVES);
         if (entry >= min(*hv_count, HEAVY_CAP)) return;
         const uint2 he = hv_list[entry];
-        worker = (block_x % (HEAVY_WORKERS / PACKET_WAVES)) * PACKET_WAVES + wave;
+        worker = (block_x % (hv_all.workers / PACKET_WAVES)) * PACKET_WAVES + wave;
         bx = he.x >> 2; wave = he.x & 3u; k_stop = he.y;
     }
     if (bx * (PACKET_THREADS * PR) >= total) return;
@@ -1321,7 +1321,7 @@ __device__ __forceinline__ void packet_search_wave(uint32_t block_x, const Table
                     const int c = __builtin_ctzll(m_chunk);
                     m_chunk &= m_chunk - 1ull;
                     const uint32_t ord = k_ord++;
-                    if (ord < k_stop || (ord - k_stop) % HEAVY_WORKERS != worker) continue;
+                    if (ord < k_stop || (ord - k_stop) % hv_all.workers != worker) continue;
                     const size_t at = ((size_t)sc * 64 + c) * 64 + lane;
                     const float4 p = tb.L1[at], ra = tb.L2[3 * at], rb = tb.L2[3 * at + 1], rc = tb.L2[3 * at + 2];
                     const float st = (KIND == 1) ? tb.L1s[at] : 0.f;
@@ -1400,7 +1400,7 @@ __device__ __forceinline__ void packet_search_wave(uint32_t block_x, const Table
 // The first launch: a workgroup per PACKET_WAVES waves of rays.  The second (HEAVY): a fixed grid whose workgroups
 // take the helpers' places in turn, HEAVY_WORKERS / PACKET_WAVES of them per entry of the list.
 #ifndef HEAVY_GRID
-#define HEAVY_GRID 2048u
+#define HEAVY_GRID 4096u
 #endif
 template <int KIND, int PR, int MODE>
 __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all, const float4 *__restrict__ ray32_all, uint32_t n_rays,
@@ -1415,7 +1415,7 @@ __global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all, 
                                             counters, sp_all, sl, list_stride, n_active_stride, hv_all);
         return;
     }
-    const uint32_t places = min(hv_all.count[sl.slot[blockIdx.y]], HEAVY_CAP) * (HEAVY_WORKERS / PACKET_WAVES);
+    const uint32_t places = min(hv_all.count[sl.slot[blockIdx.y]], HEAVY_CAP) * (hv_all.workers / PACKET_WAVES);
     for (uint32_t b = blockIdx.x; b < places; b += gridDim.x)
         packet_search_wave<KIND, PR, 2>(b, t_all, ray32_all, n_rays, active_rid_all, n_active_all, cand_all, cand_cnt_all,
                                            counters, sp_all, sl, list_stride, n_active_stride, hv_all);
@@ -4201,6 +4201,8 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             const bool two_launches = sc->view.n_prims >= heavy_min_prims;
             Heavy hv = w.heavy;
             hv.after = getenv("RT355_HEAVY_AFTER") ? (uint32_t)atoi(getenv("RT355_HEAVY_AFTER")) : HEAVY_AFTER; // (tests: hand over early)
+            hv.workers = getenv("RT355_HEAVY_WORKERS") ? (uint32_t)atoi(getenv("RT355_HEAVY_WORKERS")) : HEAVY_WORKERS;
+            hv.workers = std::max<uint32_t>(PACKET_WAVES, hv.workers / PACKET_WAVES * PACKET_WAVES);
             if (two_launches) HIP_TRY(hipMemsetAsync(w.heavy.count, 0, LIGHT_GROUP * sizeof(uint32_t), st));
 #define PACKET_ARGS sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride, hv
 #define LAUNCH_PACKET(K, P) do { \
