@@ -25,7 +25,14 @@ total) or one frame between them (--shard slabs: contiguous row slabs; --shard t
 tiles; a fixed total), followed by the only exchange of the path: the gather of the final frame over RCCL
 and its readback on rank 0.
 
-Prints ONE JSON line on rank 0.
+Prints ONE compact JSON line on rank 0 as the last thing the run writes (a few kilobytes: headline, its roofline
+and CPU baseline, five numbers per other workload, the scaling workloads); the full record of every workload goes to
+bench_detail.json beside this script (and to gpurun_out/ where that directory exists).  Progress lines go to stderr
+before it, prefixed "bench:".
+
+The scaling workloads -- the million-triangle 8K frame and the 10 000-sphere 4K frame in interleaved 32-row tiles, and
+the 60-camera sweep -- are measured after the headline at every N: at N = 1 the one GPU renders all of each, at N > 1
+the ranks share them ("scaling_workloads" of the line).
 """
 from __future__ import annotations
 
@@ -49,12 +56,16 @@ ALGO_FLOPS = {"sphere": 18.0, "plane": 14.0, "tri_front": 50.0, "tri_culled": 13
 # flops the search kernel EXECUTES per pair: 3 FMA (6) + its share of the max-fold (8 max3 per
 # 16 pairs, 2 compares each = 1) + 1/16 of the group compare
 EXEC_FLOPS_PER_PAIR = 6.0 + 1.0 + 1.0 / 16.0
-TRAFFIC_FILE = "r2_traffic.json"
+TRAFFIC_FILES = ("r3_traffic.json", "r2_traffic.json")  # the newest summary that holds the pair
+ISSUE_FILE = "r3_issue.json"
+SIMDS = 1024               # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9           # peak engine clock
+LINE_LIMIT = 8000          # the final line stays below this many bytes
 
 
 def build_workload(name: str):
     from raytracer_amd import scenes as S
-    if name == "spheres10k_8lights_4k":
+    if name in ("spheres10k_8lights_4k", "spheres10k_tiles"):  # _tiles: one frame shared between the ranks
         w, h = 3840, 2160
         return S.spheres_scene(10000, seed=355), S.spheres_shader(8), S.default_camera(w, h), w, h
     if name in ("default_4k", "default_bleed162_4k"):
@@ -122,7 +133,7 @@ def sweep_of(name: str, w: int, h: int):
 
 
 # the partition a workload is meant for when --shard is left at its default
-DEFAULT_SHARD = {"mesh1m_8k_tiles": "tiles", "mesh1m_8k_slabs": "slabs"}
+DEFAULT_SHARD = {"mesh1m_8k_tiles": "tiles", "mesh1m_8k_slabs": "slabs", "spheres10k_tiles": "tiles"}
 
 
 def gather_of(name: str):
@@ -190,7 +201,7 @@ def cpu_baseline(scene, shader, cam, w, h, stride, threads, shading=0, dirs=None
             raise SystemExit(f"parity: {ndiff} of the {a.shape[0] * a.shape[1]} pixels the CPU checker sampled differ from the GPU frame")
         parity = "ok"
     out = {"value": count_rays(st) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-           "parity_sample": parity,
+           "parity_sample": parity, "sample_short": f"every {stride}th pixel in x and y of the same frame, {dt:.2f} s",
            "sample": f"every {stride}th pixel in x and y of the same frame ({st['primary_rays']} primary + "
                      f"{st['shadow_rays']} shadow + {st['gather_rays']} gather + {st['secondary_rays']} mirror or refracted rays, {dt:.2f} s)"}
     # one thread of the same port, on a sample a thread finishes in seconds
@@ -248,13 +259,34 @@ def measured_traffic(workload, kernel):
     and --pmc WRITE_SIZE, separate passes of this same bench command: tools/traffic_passes.sh), read from the
     committed summary; FETCH_SIZE doubled, as gfx950 tallies a 128-byte request as 64 bytes.  None when the
     summary does not hold the pair."""
-    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    for name in TRAFFIC_FILES:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))[workload][kernel]
+        except (OSError, KeyError, ValueError):
+            continue
+        return {"bytes": (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0, "fetch_kib_counter": rec["fetch_kb"],
+                "write_kib_counter": rec["write_kb"], "source": "profiles/" + name}
+    return None
+
+
+def measured_issue(workload, kernel, avg_launch_ms):
+    """Share of the chip's vector-issue slots a launch of `kernel` on `workload` used: wave-level vector instructions
+    per launch as the SQ counters gave them (rocprofv3 --pmc SQ_ACTIVE_INST_VALU ..., a separate pass of this same
+    bench command: tools/pmc_pass.sh, summarised by tools/issue_merge.py into the committed file), four cycles each,
+    over the cycles 1 024 SIMDs have in the launch's duration as THIS run measured it.  None when the summary does
+    not hold the pair."""
+    path = os.path.join(ROOT, "profiles", ISSUE_FILE)
     try:
         rec = json.load(open(path))[workload][kernel]
     except (OSError, KeyError, ValueError):
         return None
-    return {"bytes": (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0, "fetch_kib_counter": rec["fetch_kb"],
-            "write_kib_counter": rec["write_kb"], "source": "profiles/" + TRAFFIC_FILE}
+    if not avg_launch_ms:
+        return None
+    inst = float(rec["valu_inst_per_launch"])
+    slots = SIMDS * CLOCK_HZ * avg_launch_ms * 1e-3 / 4.0
+    return {"bound": "valu_issue", "kernel": kernel, "achieved": round(inst / (avg_launch_ms * 1e-3) / 1e12, 4), "peak": round(SIMDS * CLOCK_HZ / 4.0 / 1e12, 4),
+            "unit": "T wave-instructions/s", "frac": round(inst / slots, 4), "traffic": None, "avg_launch_ms": round(avg_launch_ms, 4),
+            "valu_inst_per_launch": inst, "profiled_avg_launch_ms": rec.get("avg_ms"), "source": "profiles/" + ISSUE_FILE}
 
 
 def run_frames(r, cam, shader, o, fb, stream, steps, detail=False):
@@ -277,14 +309,14 @@ def run_frames(r, cam, shader, o, fb, stream, steps, detail=False):
     return acc, stats
 
 
-def measure(name, args, ctx):
+def measure(name, args, ctx, light=False):
     """One workload: W warm-up steps, K timed steps between barriers (max over ranks), then, on rank 0 and
     outside the timed region, the device-resident figure, kernel-time breakdown, rooflines, the all-pairs
-    comparison and the CPU baseline."""
+    comparison and the CPU baseline (light=True: the timed steps alone)."""
     import torch
     from raytracer_amd import binding as B
     from raytracer_amd.api import HostPixmap, Renderer
-    from raytracer_amd.sharding import SharedPixmap, frames_for_rank, gather_frame, rows_of, TILE_ROWS
+    from raytracer_amd.sharding import SharedPixmap, frames_for_rank, gather_frame, host_barrier, rows_of, TILE_ROWS
     dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
 
     scene, shader, cam, w, h = build_workload(name)
@@ -324,13 +356,13 @@ def measure(name, args, ctx):
                 rc = rt355_render(*part_args)
                 if rc:
                     _check(rc, "rt355_render")
-                dist.barrier()
+                host_barrier(dist)
                 st = st_part.as_dict()
                 return count_rays(st), st
             # this rank's rows into its framebuffer in HBM, the final frame gathered on rank 0 (RCCL), read back there
             r.render_device(cam, shader, o_part, fb.data_ptr(), stream)
             st = r.sync()
-            full = gather_frame(fb, rank, world, dst=0, shard=shard)
+            full = gather_frame(fb, rank, world, dst=0, shard=shard, group=ctx["gpu_group"])
             if rank == 0:
                 host_t.copy_(full)
             return count_rays(st), st
@@ -381,7 +413,7 @@ def measure(name, args, ctx):
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            host_barrier(dist)
         torch.cuda.synchronize()
 
     import gc
@@ -465,12 +497,14 @@ def measure(name, args, ctx):
                       "gather_directions": 0 if dirs is None else len(dirs),
                       "candidates_evaluated_fp64": stats["exact_tests"], "overflow_rays": stats["overflow_rays"],
                       "packet_survivors": stats["packet_survivors"]}}
-    if world > 1:  # the breakdowns below describe one GPU rendering whole frames
-        if split:  # the frame the ranks assembled against the same frame rendered by this rank alone (outside the timed region)
-            r.render_device(cam, shader, o, fb.data_ptr(), stream)
-            r.sync()
-            out["gathered_frame"] = "ok" if np.array_equal(fb.cpu().numpy(), gpu_frame) else "DIFFERS"
-            assert out["gathered_frame"] == "ok", "the frame gathered from the ranks differs from the frame one rank renders"
+    if split:  # the frame the ranks assembled against the same frame rendered by this rank alone (outside the timed region)
+        r.render_device(cam, shader, o, fb.data_ptr(), stream)
+        r.sync()
+        out["gathered_frame"] = "ok" if np.array_equal(fb.cpu().numpy(), gpu_frame) else "DIFFERS"
+        assert out["gathered_frame"] == "ok", "the frame gathered from the ranks differs from the frame one rank renders"
+    # the breakdowns below describe one GPU rendering whole frames: rank 0 makes them for frames it rendered whole (no
+    # collective in them; the other ranks wait at the next workload's first barrier)
+    if light or split or (world > 1 and cams is not None):
         r.close()
         host.close()
         return out
@@ -524,11 +558,14 @@ def measure(name, args, ctx):
         # a frame rendered level by level: the launches of all levels are summed in kernel_time (search includes
         # k_search_general, resolve_primary is level 0's, shade the rest); the per-kernel byte models below describe
         # one level and are not applied
-        out["roofline"] = {"bound": "hbm", "kernel": "k_gather_walk" if stats["gather_rays"] > 0 else "levels", "achieved": None,
-                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                           "note": ("one launch walks the scene table for every gather ray; bound by instruction issue, not by HBM: "
-                                    "see profiles/ for its trace and counters" if stats["gather_rays"] > 0 else
-                                    "multi-level frame: see profiles/ for the per-kernel trace")}
+        if stats["gather_rays"] > 0:  # one launch walks the scene table for every gather ray
+            kern, avg_ms = "k_gather_walk", acc["search_ms"] / max(1, acc["search_launches"])
+            avg_ms = max(r.search_launch_ms()) if acc["search_launches"] else avg_ms  # (the walk is the long one of the frame's search launches)
+        else:  # a frame of several levels: its shading launches are the largest share
+            kern, avg_ms = "k_shade_group", acc["shade_ms"] / max(1, acc["shade_launches"])
+        out["roofline"] = measured_issue(name, kern, avg_ms) or {
+            "bound": "valu_issue", "kernel": kern, "achieved": None, "peak": round(SIMDS * CLOCK_HZ / 4.0 / 1e12, 4), "unit": "T wave-instructions/s",
+            "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 4), "note": "no counter pass of this kernel in profiles/" + ISSUE_FILE}
     elif not searched:
         # k_render_direct: the reference's own algorithm (every primitive tested for the camera ray and for every
         # shadow ray, fp64), one thread per pixel.  Priced as the reference-formula flops of those tests against
@@ -540,10 +577,11 @@ def measure(name, args, ctx):
         refracts = bool((scene.pack().objects["fresnel"] < 1).any()) and not shading
         if refracts and scene.n_primitives >= 64:
             # every ray of the pixel's tree walks the scene table: the tests are those of the walk, not one per primitive
-            out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_refract", "achieved": None, "peak": PEAK_FP32_TFLOPS,
-                               "unit": "TFLOP/s", "frac": None, "traffic": None, "launches_per_frame": 1, "avg_launch_ms": round(avg_ms, 4),
-                               "box_tests_per_frame": stats["pair_tests"], "candidates_evaluated_fp64": stats["exact_tests"],
-                               "note": "one kernel per frame that walks the scene table for every ray; bound by instruction issue"}
+            out["roofline"] = measured_issue(name, "k_render_refract", avg_ms) or {
+                "bound": "valu_issue", "kernel": "k_render_refract", "achieved": None, "peak": round(SIMDS * CLOCK_HZ / 4.0 / 1e12, 4),
+                "unit": "T wave-instructions/s", "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "note": "no counter pass of this kernel in profiles/" + ISSUE_FILE}
+            out["roofline"].update({"launches_per_frame": 1, "box_tests_per_frame": stats["pair_tests"], "candidates_evaluated_fp64": stats["exact_tests"]})
         else:
             out["roofline"] = {"bound": "valu_fp32", "kernel": "k_render_gather" if shading else ("k_render_refract" if refracts else "k_render_direct"), "achieved": round(tf, 3),
                                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 5),
@@ -567,6 +605,10 @@ def measure(name, args, ctx):
             rooflines["k_search_packet"] = hbm_roofline("k_search_packet", sb, acc["search_ms"], acc["search_launches"])
         times = {"k_resolve_primary": acc["primary_ms"], "k_shade_group": acc["shade_ms"],
                  "k_search_packet": acc["search_ms"], "k_search": acc["search_ms"]}
+        for k, rf in rooflines.items():  # what the counters say bounds them: instruction issue, beside the HBM floor
+            iss = measured_issue(name, k, rf["avg_launch_ms"])
+            if iss:
+                rf["valu_issue_frac"] = iss["frac"]
         dominant = max(rooflines, key=lambda k: times[k])
         out["roofline"] = rooflines[dominant]
         out["roofline_other_kernels"] = {k: v for k, v in rooflines.items() if k != dominant}
@@ -603,9 +645,191 @@ def measure(name, args, ctx):
     return out
 
 
+def measure_inproc(name, args, devices):
+    """One workload through ONE process driving len(devices) GPUs (rt355_scene_create_multi): a frame's 32-row tiles
+    dealt to the GPUs, every GPU writing its rows into the one page-locked pixmap; a sweep's frames dealt round robin.
+    The headline (whole frames, weak scaling) is a sweep of one frame per GPU.  Outside the timed region the result is
+    compared with what one GPU renders alone."""
+    import torch
+    from raytracer_amd import binding as B
+    from raytracer_amd.api import HostPixmap, Renderer
+    scene, shader, cam, w, h = build_workload(name)
+    shading, dirs = gather_of(name)
+    cams = sweep_of(name, w, h)
+    n = len(devices)
+    weak = cams is None and DEFAULT_SHARD.get(name) is None  # whole frames, one per GPU and step
+    if weak:
+        cams = [cam] * n
+    r = Renderer(scene, devices=devices)
+    if dirs is not None:
+        r.set_directions(dirs)
+    if args.gather == "xgmi":
+        r.set_option("gather", 1)
+    o = B.opts(w, h, mode=B.MODE_PACKET if args.mode == "packet" else B.MODE_ALLPAIRS, shading=shading)
+    pix = [HostPixmap(w, h) for _ in (cams or [None])]
+    arrays = [p.array for p in pix]
+
+    def step():
+        if cams is not None:
+            return r.render_sweep(cams, shader, o, arrays)
+        return [r.render(cam, shader, w, h, mode=o.mode, shading=shading, out=arrays[0])[1]]
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sts = step()
+    dt = time.perf_counter() - t0
+    rays = sum(count_rays(st) for st in sts)
+    last = arrays[-1].copy()
+    for p in pix:
+        p.close()
+    r.close()
+    torch.cuda.set_device(devices[0])
+    alone = Renderer(scene)
+    if dirs is not None:
+        alone.set_directions(dirs)
+    want, _ = alone.render((cams or [cam])[-1], shader, w, h, mode=o.mode, shading=shading)
+    alone.close()
+    same = bool(np.array_equal(want, last))
+    assert same, "the frame the GPUs of one process rendered together differs from the frame one GPU renders"
+    return {"value": round(rays * args.steps / dt / 1e6, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 4), "scaling": "weak" if weak else "strong", "gathered_frame": "ok",
+            "timed": "one process, rt355_scene_create_multi over %d devices: %s" % (n, "rt355_render_sweep" if cams is not None else "rt355_render"),
+            "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives, "lights": len(shader.lights), "alias": 0,
+                       "shard": "frames" if cams is not None else "tiles", "frames_per_step": len(cams) if cams is not None else 1, "search": args.mode,
+                       "rays_per_frame": {"primary": sts[-1]["primary_rays"], "shadow": sts[-1]["shadow_rays"],
+                                          "gather": sts[-1]["gather_rays"], "mirror": sts[-1]["secondary_rays"]}}}
+
+
+def run_inproc(args):
+    """`--inproc`: the headline and the scaling workloads through one process that drives all N GPUs."""
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    share = bool(os.environ.get("RT355_BENCH_SHARE_GPU"))
+    devices = [0] * args.gpus if share else list(range(args.gpus))
+    assert share or torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but {torch.cuda.device_count()} devices"
+    torch.cuda.set_device(devices[0])
+    out = {}
+    names = [args.workload] + (SCALING if args.workload == HEADLINE and not args.no_scaling else [])
+    for name in names:
+        t0 = time.perf_counter()
+        out[name] = measure_inproc(name, args, devices)
+        print(f"bench: in-process {name} {out[name]['ms_per_step']} ms per step ({time.perf_counter() - t0:.1f} s)", file=sys.stderr, flush=True)
+    head = out[args.workload]
+    line = compact_line(head, {}, {k: v for k, v in out.items() if k != args.workload}, args.gpus, args.steps, args.warmup)
+    line["launch"] = "one process, %d devices" % args.gpus
+    emit(line, dict(line, headline=head, scaling_workloads_detail=out), detail_name="bench_detail_inproc.json")
+    return 0
+
+
+def inproc_beside(args, world):
+    """After the ranks' own measurements: the same headline and scaling workloads by ONE process that drives all N GPUs
+    (a child process: the ranks are idle meanwhile), so that one run shows both ways of reaching N GPUs.  A failure
+    is reported in the record, not raised."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--inproc", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--gather", args.gather, "--mode", args.mode]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within 420 s"}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": (p.stderr or "no output")[-300:]}
+    d = json.loads(lines[-1])
+    out = {"ms": d["ms_per_step"], "value": d["value"], "scaling": d["scaling"]}
+    for name, e in d.get("scaling_workloads", {}).items():
+        out[name] = {"ms": e["ms"], "value": e["value"], "gathered_frame": e.get("gathered_frame")}
+    return out
+
+
 HEADLINE = "default_4k"
-OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "mesh100k_sweep60", "default_bleed162_4k",
+OTHERS = ["spheres10k_8lights_4k", "mesh100k_2lights_4k", "default_bleed162_4k",
           "spheres10k_mirrors_8lights_4k", "glass_room_4k", "spheres10k_glass_8lights_4k", "mesh100k_bleed42_4k"]
+# measured after the headline at every N: one frame in interleaved tiles between the ranks (BASELINE configs[3] and
+# configs[2]'s scene), and the camera sweep dealt round robin (configs[4]); at N = 1 the one GPU renders all of each
+SCALING = ["mesh1m_8k_tiles", "spheres10k_tiles", "mesh100k_sweep60"]
+
+
+def _num(x, digits=4):
+    return None if x is None else round(float(x), digits)
+
+
+def compact_roofline(rf):
+    """The roofline object of the line: the contract's keys and the launch time they were measured with."""
+    out = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")}
+    if "valu_issue_frac" in rf:
+        out["valu_issue_frac"] = rf["valu_issue_frac"]
+    return out
+
+
+def compact_cpu(cb):
+    out = {"value": _num(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+           "sample": cb.get("sample_short", cb.get("sample", ""))[:120], "parity_sample": cb.get("parity_sample")}
+    if "one_thread" in cb:
+        out["one_thread"] = _num(cb["one_thread"]["value"])
+    if "reference_classes_one_thread" in cb:  # the reference's own classes (oracle/_ref), one thread
+        out["reference_one_thread"] = _num(cb["reference_classes_one_thread"]["value"])
+    return out
+
+
+def compact_line(head, others, scaling, world, steps, warmup):
+    """The ONE line the run ends with: BASELINE's metric on the headline workload with its roofline and CPU baseline,
+    five numbers per other workload, the scaling workloads.  Everything else is in bench_detail.json."""
+    out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",
+           "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": head["ms_per_step"],
+           "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
+           "dtype": "f64" if head["config"]["primitives"] < 64 else "f32 search + f64 resolve", "data": "synthetic"}
+    c = head["config"]
+    out["config"] = {k: c[k] for k in ("workload", "width", "height", "primitives", "lights", "alias", "shard", "search",
+                                       "frames_per_step", "rays_per_frame") if k in c}
+    for k in ("gathered_frame", "value_device_resident", "ms_per_step_device_resident"):
+        if k in head:
+            out[k] = head[k]
+    if "readback" in head:
+        out["readback_link_GBps"] = head["readback"]["link_GBps"]
+    if "roofline" in head:
+        out["roofline"] = compact_roofline(head["roofline"])
+    if "cpu_baseline" in head:
+        out["cpu_baseline"] = compact_cpu(head["cpu_baseline"])
+    if others:
+        out["configs"] = {}
+        for name, d in others.items():
+            rf = d.get("roofline", {})
+            e = {"ms": d["ms_per_step"], "value": d["value"], "kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"),
+                 "parity": d.get("cpu_baseline", {}).get("parity_sample")}
+            if "all_pairs" in d:  # the all-pairs search of the same frame: the FP32-VALU-bound kernel
+                e["allpairs_fp32_frac"] = d["all_pairs"]["roofline"]["frac"]
+            out["configs"][name] = e
+    if scaling:
+        out["scaling_workloads"] = {}
+        for name, d in scaling.items():
+            e = {"ms": d["ms_per_step"], "value": d["value"], "scaling": d["scaling"], "shard": d["config"]["shard"]}
+            if "gathered_frame" in d:
+                e["gathered_frame"] = d["gathered_frame"]
+            out["scaling_workloads"][name] = e
+    out["detail"] = "bench_detail.json"
+    return out
+
+
+def emit(line: dict, detail: dict, detail_name: str = "bench_detail.json"):
+    """bench_detail.json first, then the line: the last thing the run writes, on stdout, with stderr flushed before it."""
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:  # (cannot happen with the fields above; the line must stay readable by a tail)
+        line = {k: v for k, v in line.items() if k not in ("configs",)}
+        text = json.dumps(line, separators=(",", ":"))
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, detail_name), "w") as f:
+                    json.dump(detail, f, indent=1)
+            except OSError:
+                pass
+    sys.stderr.flush()
+    print(text, flush=True)
+    return text
 
 
 def spawn_ranks(n: int) -> int:
@@ -669,16 +893,22 @@ def main():
     ap.add_argument("--mode", choices=["packet", "allpairs"], default="packet",
                     help="search of searched scenes: packet = beams against a direction-sorted table "
                          "(library default); allpairs = fp32 test of every ray/primitive pair")
-    ap.add_argument("--no-others", action="store_true", help="only the workload named, no other_configs")
+    ap.add_argument("--no-others", action="store_true", help="no other workloads after the headline (\"configs\" of the line)")
+    ap.add_argument("--no-scaling", action="store_true", help="no scaling workloads after the headline (\"scaling_workloads\")")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--in-flight", type=int, default=2, help="sweep workloads: frames in flight per rank (scene handles)")
+    ap.add_argument("--inproc", action="store_true",
+                    help="N > 1 through ONE process that drives all N GPUs (rt355_scene_create_multi) instead of one rank per GPU")
+    ap.add_argument("--no-inproc", action="store_true", help="N > 1: do not measure the one-process way beside the ranks' own")
     ap.add_argument("--check-launch", action="store_true",
                     help="start the ranks, meet over gloo, print {\"launch\": \"ok\", ...} and stop: no GPU is touched")
     args = ap.parse_args()
 
+    if args.inproc:
+        sys.exit(run_inproc(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))  # (before anything in this process touches the GPU)
     if args.check_launch:
@@ -701,38 +931,36 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = {"dist": dist, "world": world, "rank": rank, "reduce_device": "cpu" if share else "cuda"}
+        # The control plane (barriers, the max-over-ranks time, the ray counts: a few numbers in host memory) runs over
+        # gloo; RCCL carries GPU tensors and is set up only where there are any to send: the gather of a frame's rows
+        # on GPU 0 (--gather xgmi).  The default path (whole frames, or rows into the one host pixmap) has no GPU collective.
+        dist.init_process_group("gloo")
+    ctx = {"dist": dist, "world": world, "rank": rank, "reduce_device": "cpu", "gpu_group": None}
+    if world > 1 and args.gather == "xgmi" and not share:
+        ctx["gpu_group"] = dist.new_group(backend="nccl")  # RCCL over xGMI: the gather of the final frame on GPU 0
 
-    def timed_measure(name):  # (a line per workload on stderr: a long default run shows that it is alive)
+    def timed_measure(name, light=False):  # (a line per workload on stderr: a long default run shows that it is alive)
         t0 = time.perf_counter()
-        res = measure(name, args, ctx)
+        res = measure(name, args, ctx, light=light)
         if rank == 0:
-            print(f"[bench] {name}: {res['ms_per_step']} ms per step, measured in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+            print(f"bench: {name} {res['ms_per_step']} ms per step ({time.perf_counter() - t0:.1f} s)", file=sys.stderr, flush=True)
         return res
 
     head = timed_measure(args.workload)
-    others = {}
+    scaling, others = {}, {}
+    if args.workload == HEADLINE and not args.no_scaling:
+        for name in SCALING:
+            scaling[name] = timed_measure(name, light=True)
     if world == 1 and args.workload == HEADLINE and not args.no_others:
         for name in OTHERS:
             others[name] = timed_measure(name)
     if rank == 0:
         # (a workload that casts gather rays counts them too)
-        out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-               "higher_is_better": True, "scaling": head["scaling"],
-               "vs_baseline": None, "dtype": "f64" if head["config"]["primitives"] < 64 else "f32 search + f64 resolve",
-               "data": "synthetic"}
-        for k in ("timed", "gathered_frame", "value_device_resident", "ms_per_step_device_resident", "readback", "config", "kernel_time", "roofline",
-                  "roofline_other_kernels", "all_pairs", "cpu_baseline"):
-            if k in head:
-                out[k] = head[k]
-        if others:
-            out["other_configs"] = others
-        print(json.dumps(out), flush=True)
+        line = compact_line(head, others, scaling, world, args.steps, args.warmup)
+        if world > 1 and args.workload == HEADLINE and not args.no_inproc and not args.no_scaling:
+            line["inproc"] = inproc_beside(args, world)
+        detail = dict(line, headline=head, other_configs=others, scaling_workloads_detail=scaling)
+        emit(line, detail)
     if world > 1:
         dist.destroy_process_group()
 

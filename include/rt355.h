@@ -259,13 +259,32 @@ typedef struct rt355_stats {
     uint64_t gather_rays;    /* gather rays cast: directions with ray . nh > 0 (shader.h:122,167) */
 } rt355_stats;
 
-typedef struct rt355_scene rt355_scene; /* opaque, library-owned, bound to one HIP device */
+typedef struct rt355_scene rt355_scene; /* opaque, library-owned; bound to one HIP device (rt355_scene_create) or
+                                           dealing its calls to one scene per device (rt355_scene_create_multi) */
 
 /* Flatten and upload a scene to the current HIP device.
  * Replaces: the object-list walk done implicitly by every CalcIntersect call through
  * vector<AnyObject*> (main.cpp:65-79); the reference has no upload step. */
 int rt355_scene_create(const rt355_scene_desc *desc, rt355_scene **out);
 void rt355_scene_destroy(rt355_scene *scene);
+
+/* The same scene on several GPUs of this process: flattened and uploaded once to each of devices[0 .. n_devices - 1]
+ * (HIP device ordinals; a device may be named more than once), for a caller that is ONE process calling setPixels
+ * once per frame, as the reference's main() is (main.cpp:640).  The handle is used like any other:
+ *   rt355_render        deals the 32-row tiles of the slab to the devices (tile k to device k mod n), every GPU
+ *                       writing its rows over its own link into the caller's one pixmap -- the kernels' own stores
+ *                       where the pixmap is page-locked (rt355_host_alloc, rt355_host_register), each device's
+ *                       staging memory and a host copy where it is not; opts->tile_count must be left at 0.
+ *                       With the option "gather" set to 1 (rt355_scene_set_option) the shares are rendered into
+ *                       HBM, copied to devices[0] over the GPUs' own links and read back from there in one transfer;
+ *   rt355_render_sweep  deals whole frames, frame f to device f mod n;
+ *   rt355_scene_set_directions, rt355_scene_set_option reach every device; statistics are summed over the devices
+ *                       (ms_device: the longest); the kernel-time queries and rt355_probe_intersect answer for
+ *                       devices[0]; rt355_render_device(_noalloc) return RT355_ERR_UNSUPPORTED (a device pixmap
+ *                       lies on one GPU).
+ * Pixels are independent given the replicated scene, so the frame is the one a single device renders, byte for byte.
+ * Replaces: setPixels(Scene, Shader, int alias) (main.cpp:339-376), as rt355_scene_create + rt355_render do. */
+int rt355_scene_create_multi(const rt355_scene_desc *desc, const int32_t *devices, int32_t n_devices, rt355_scene **out);
 
 /* Render rows [row_begin,row_end) into a caller-owned HOST pixmap of width*height*3
  * bytes, RGB, row 0 = bottom scanline, index (y*width+x)*3.
@@ -283,8 +302,10 @@ int rt355_render_device(rt355_scene *scene, const rt355_camera *cam,
                         const rt355_shader *shader, const rt355_opts *opts,
                         void *d_pixmap, void *hip_stream, rt355_stats *stats);
 
-/* rt355_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  It calls no hipMalloc / hipFree /
+/* rt355_render_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc,
+ * processes whose device memory is spoken for).  No counterpart in the reference.  Not for use while the stream is
+ * being captured into a HIP graph: like rt355_render_device it records timing events and enqueues the copy of its
+ * statistics, which the next call on the handle waits for.  It calls no hipMalloc / hipFree /
  * hipHostMalloc or other allocating routine: the device memory the kernels need beyond the scene, the
  * lights and the pixmap -- the statistics counters, the device copy of the light list and, with alias > 0,
  * the sub-sample colours -- lives in an array inside the library's code object (RT355_NOALLOC_BYTES, about
@@ -360,6 +381,27 @@ int rt355_abi_version(void);
 double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim);
 double rt355_rotation(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t axis);
 double rt355_strata(uint32_t seed, int32_t x, int32_t y, int32_t which);
+
+/* Tuning options of a scene handle, by name.  No counterpart in the reference.  Their initial values are read from the
+ * environment once, when the handle is created (RT355_<NAME IN CAPITALS>, e.g. RT355_TAIL_PARTS=1); no render call
+ * reads the environment.  None of them changes a frame's bytes.
+ *   "readback"        rt355_render into a page-locked pixmap: 0 = the handle times both ways on its first frames of
+ *                     a kind and keeps the faster (default), 1 = the kernels write the pixmap directly over the link,
+ *                     2 = rendered into HBM and copied in parts
+ *   "render_parts"    parts a one-kernel frame is rendered and copied in (default 6)
+ *   "tail_parts"      parts the last stage of a searched frame is shaded and copied in (default 4); "no_tail_parts" 1
+ *                     = such a frame is enqueued and copied whole
+ *   "packet_rays"     rays per lane of the packet search, 1 or 4 (default 0: both are timed on the first frames)
+ *   "heavy_min_prims" the packet search runs as two launches from this many primitives (default 300000; 0 = always),
+ *   "heavy_after"     a wave handing the rest of its walk over after this many primitives (default 256)
+ *   "heavy_workers"   to this many waves (default 16)
+ *   "gather_general"  1 = the gather shaders' general kernel also for scenes of at most four planes and spheres
+ *   "walk_blocks"     workgroups of the searched gather's walk (default 8192)
+ *   "gather"          multi-device scenes only: 0 = every GPU writes its rows into the host pixmap (default), 1 = rows
+ *                     gathered on the first device and read back from there
+ *   "tail_bottom_first", "tail_even", "copy_streams", "last_copied", "no_copy_prime", "debug_readback": measurement aids
+ * RT355_ERR_ARG for a name that is not listed or a value out of range. */
+int rt355_scene_set_option(rt355_scene *scene, const char *name, int64_t value);
 
 /* The direction set of the gather shaders: the global `geo` that main.cpp:639 fills from Geodesic()
  * (main.cpp:408-450: the `v` lines of an OBJ file, centred on their mean and normalised).  xyz holds n

@@ -38,6 +38,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.rt355_last_error.restype = C.c_char_p
         L.rt355_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt355_scene_create_multi.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
         L.rt355_scene_destroy.argtypes = [C.c_void_p]
         L.rt355_scene_destroy.restype = None
         L.rt355_render.argtypes = [C.c_void_p] * 6
@@ -60,6 +61,7 @@ def lib():
         L.rt355_probe_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.rt355_probe_sincos.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rt355_scene_set_directions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.rt355_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rt355_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
@@ -71,13 +73,19 @@ def _check(rc: int, what: str):
 
 
 class Renderer:
-    """A scene uploaded to the current HIP device (rt355_scene_create)."""
+    """A scene uploaded to the current HIP device (rt355_scene_create) or, with devices=[...], to several GPUs of this
+    process (rt355_scene_create_multi): render / render_sweep then share every frame / every sweep between them."""
 
-    def __init__(self, scene):
+    def __init__(self, scene, devices=None):
         self.packed = scene.pack() if isinstance(scene, Scene) else scene
         assert isinstance(self.packed, PackedScene)
         self.handle = C.c_void_p()
-        _check(lib().rt355_scene_create(C.byref(self.packed.desc), C.byref(self.handle)), "rt355_scene_create")
+        if devices is None:
+            _check(lib().rt355_scene_create(C.byref(self.packed.desc), C.byref(self.handle)), "rt355_scene_create")
+        else:
+            devs = (C.c_int32 * len(devices))(*devices)
+            _check(lib().rt355_scene_create_multi(C.byref(self.packed.desc), devs, len(devices), C.byref(self.handle)),
+                   "rt355_scene_create_multi")
         self._stats = CStats()
 
     def close(self):
@@ -118,6 +126,10 @@ class Renderer:
         d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
         _check(lib().rt355_scene_set_directions(self.handle, d.ctypes.data if len(d) else None, len(d)),
                "rt355_scene_set_directions")
+
+    def set_option(self, name: str, value: int):
+        """rt355_scene_set_option: a tuning option of the handle (include/rt355.h lists them)."""
+        _check(lib().rt355_scene_set_option(self.handle, name.encode(), int(value)), "rt355_scene_set_option")
 
     def render_device(self, cam, shader: Shader, o: COpts, d_pixmap: int, stream: int = 0):
         """Device framebuffer path (rt355_render_device): enqueue only; call sync() for stats."""

@@ -34,15 +34,18 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "../../include/rt355.h"
 #include "rt_exact.h"
 
-#define RT_ABI_VERSION 6
+#define RT_ABI_VERSION 7
 #define SEARCH_THREADS 256
 #ifndef RAYS_PER_THREAD
 #define RAYS_PER_THREAD 4   // rays per lane of the search kernel (2, 4 or 8)
@@ -3281,8 +3284,63 @@ inline double4 index_rec(int32_t obj, int32_t tri) { // (obj, tri) in the first 
 inline uint32_t pack_rgb(const uint8_t *c) { return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16); }
 } // namespace
 
+// Tuning options of a scene handle (rt355_scene_set_option).  Their initial values come from the environment, read
+// once when the handle is made (RT355_<NAME IN CAPITALS>); nothing on the per-frame path reads the environment.
+struct Knobs {
+    int64_t heavy_min_prims = HEAVY_MIN_PRIMS; // packet search in two launches from this many primitives (0: always)
+    int64_t heavy_after = HEAVY_AFTER;         // ... a wave hands over after this many primitives met
+    int64_t heavy_workers = HEAVY_WORKERS;     // ... to this many waves
+    int64_t packet_rays = 0;                   // rays per lane of the packet search: 1 or 4 (0: timed on the first frames)
+    int64_t gather_general = 0;                // 1: the gather shaders' general kernel also for scenes of a few planes and spheres
+    int64_t walk_blocks = 8192;                // workgroups of the searched gather's walk
+    int64_t readback = 0;                      // rt355_render into a page-locked pixmap: 0 timed per kind of frame, 1 kernels write it, 2 copied in parts
+    int64_t render_parts = 6;                  // ... parts of a one-kernel frame that is copied
+    int64_t tail_parts = 4;                    // ... parts of a searched frame's last stage
+    int64_t no_tail_parts = 0;                 // ... 1: a searched frame is enqueued and copied as a whole
+    int64_t tail_bottom_first = 0, tail_even = 0, copy_streams = 2, last_copied = 0, no_copy_prime = 0; // (measurement aids)
+    int64_t debug_readback = 0;                // 1: the handle prints its rt355_render call times when it is destroyed
+};
+struct KnobName { const char *name; int64_t Knobs::*field; int64_t lo, hi; };
+static const KnobName kKnobs[] = {
+    {"heavy_min_prims", &Knobs::heavy_min_prims, 0, INT32_MAX}, {"heavy_after", &Knobs::heavy_after, 1, INT32_MAX},
+    {"heavy_workers", &Knobs::heavy_workers, 1, 1024}, {"packet_rays", &Knobs::packet_rays, 0, 4},
+    {"gather_general", &Knobs::gather_general, 0, 1}, {"walk_blocks", &Knobs::walk_blocks, 1, 1 << 20},
+    {"readback", &Knobs::readback, 0, 2}, {"render_parts", &Knobs::render_parts, 1, 64}, {"tail_parts", &Knobs::tail_parts, 1, 64},
+    {"no_tail_parts", &Knobs::no_tail_parts, 0, 1}, {"tail_bottom_first", &Knobs::tail_bottom_first, 0, 1},
+    {"tail_even", &Knobs::tail_even, 0, 1}, {"copy_streams", &Knobs::copy_streams, 1, 2}, {"last_copied", &Knobs::last_copied, 0, 1},
+    {"no_copy_prime", &Knobs::no_copy_prime, 0, 1}, {"debug_readback", &Knobs::debug_readback, 0, 1},
+};
+static int set_knob(Knobs &k, const char *name, int64_t value) {
+    for (const KnobName &kn : kKnobs)
+        if (!strcmp(kn.name, name)) {
+            if (value < kn.lo || value > kn.hi || (kn.field == &Knobs::packet_rays && !(value == 0 || value == 1 || value == 4)))
+                return fail(RT355_ERR_ARG, std::string("option ") + name + ": value out of range");
+            k.*(kn.field) = value;
+            return RT355_OK;
+        }
+    return fail(RT355_ERR_ARG, std::string("unknown option ") + name);
+}
+static Knobs knobs_from_environment() {
+    Knobs k;
+    for (const KnobName &kn : kKnobs) {
+        std::string env = "RT355_";
+        for (const char *c = kn.name; *c; c++) env += (char)toupper((unsigned char)*c);
+        if (const char *e = getenv(env.c_str())) {
+            // (the former switches RT355_READBACK_COPY / RT355_READBACK_DIRECT are readback = 2 / 1)
+            const int64_t v = *e ? strtoll(e, nullptr, 0) : 1;
+            (void)set_knob(k, kn.name, v); // a value out of range is ignored
+        }
+    }
+    if (getenv("RT355_READBACK_COPY")) k.readback = 2;
+    if (getenv("RT355_READBACK_DIRECT")) k.readback = 1;
+    return k;
+}
+
+struct MultiScene;
 struct rt355_scene {
+    MultiScene *multi = nullptr; // rt355_scene_create_multi: this handle only deals calls to one scene per device
     int device = 0;
+    Knobs knobs{};
     SceneView view{};
     int n_padded = 0;
     bool has_tris = false;
@@ -3319,7 +3377,6 @@ struct rt355_scene {
     // best time seen with 4 and with 1 ray per lane (< 0 = not tried yet), and what each launch of the
     // outstanding frame used
     double tune_ms[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
-    int forced_packet_rays = 0; // RT355_PACKET_RAYS=1|4 pins the choice (tests)
     std::vector<std::pair<int, int>> launch_choice; // (kind of launch, rays per lane) per search launch
     // rt355_render (host pixmap): the device framebuffer kept from call to call, the stream the readback runs on
     // beside the rendering of the next part of the frame, and page-locked staging for pixmaps that are pageable
@@ -3343,6 +3400,24 @@ struct rt355_scene {
     bool pending = false;
 };
 
+// One scene on several GPUs of this process (rt355_scene_create_multi, below): a scene and a host thread per device.
+#define MULTI_TILE_ROWS 32
+#define MULTI_MAX_DEVICES 64
+struct MultiWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, quit = false;
+    int rc = RT355_OK;
+    std::string err;
+};
+struct MultiScene {
+    std::vector<rt355_scene *> scenes;
+    std::vector<int> devices;
+    std::vector<std::unique_ptr<MultiWorker>> workers;
+    int gather = 0; // 0: every GPU writes its rows into the host pixmap; 1: rows gathered on the first GPU, one readback
+};
 extern "C" const char *rt355_last_error(void) { return g_err.c_str(); }
 extern "C" int rt355_abi_version(void) { return RT_ABI_VERSION; }
 extern "C" double rt355_jitter(uint32_t seed, int32_t x, int32_t y, int32_t sample, int32_t dim) {
@@ -3718,7 +3793,8 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     kind_prims.insert(kind_prims.end(), by_kind[4].begin(), by_kind[4].end());
     kind_prims.insert(kind_prims.end(), by_kind[2].begin(), by_kind[2].end());
     rt355_scene *sc = new rt355_scene();
-    if (getenv("RT355_DEBUG_READBACK")) sc->debug_series.reserve(4096);
+    sc->knobs = knobs_from_environment();
+    if (sc->knobs.debug_readback) sc->debug_series.reserve(4096);
     // everything after `new` runs inside one function, so that any failure takes the one cleanup path below
     auto init = [&]() -> int {
     HIP_TRY(hipGetDevice(&sc->device));
@@ -3735,10 +3811,6 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->view.n_envs = (int)by_kind[3].size(); sc->view.n_quadrics = (int)by_kind[4].size();
     sc->n_padded = ((sc->view.n_prims + PRIM_TILE - 1) / PRIM_TILE) * PRIM_TILE;
     if (sc->n_padded == 0) sc->n_padded = PRIM_TILE;
-    if (const char *e = getenv("RT355_PACKET_RAYS")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 4) sc->forced_packet_rays = v;
-    }
     sc->n_table = (sc->n_padded + 4095) / 4096 * 4096;
     sc->tables.n_table = sc->n_table;
     sc->tables.top_stride = (sc->n_table / 4096 + 63) / 64 * 64;
@@ -3805,9 +3877,15 @@ static void free_work(rt355_scene *sc) {
     sc->work_slots = 0;
 }
 
+static void multi_destroy(rt355_scene *sc);
+static int multi_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader, const rt355_opts *opts,
+                        unsigned char *pixmap, rt355_stats *stats);
+static int multi_sweep(rt355_scene *sc, const rt355_camera *cams, int32_t n_frames, const rt355_shader *shader,
+                       const rt355_opts *opts, unsigned char *const *pixmaps, rt355_stats *stats);
 extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (!sc) return;
-    if (getenv("RT355_DEBUG_READBACK") && sc->debug_calls[0] + sc->debug_calls[1])
+    if (sc->multi) { multi_destroy(sc); return; }
+    if (sc->knobs.debug_readback && sc->debug_calls[0] + sc->debug_calls[1])
         fprintf(stderr, "[rt355] rt355_render calls: %llu direct, mean %.3f ms; %llu copied in parts, mean %.3f ms\n",
                 (unsigned long long)sc->debug_calls[0], sc->debug_ms[0] / (double)std::max<uint64_t>(1, sc->debug_calls[0]),
                 (unsigned long long)sc->debug_calls[1], sc->debug_ms[1] / (double)std::max<uint64_t>(1, sc->debug_calls[1]));
@@ -3851,7 +3929,9 @@ static int slots_for(uint32_t n_rays, int n_lights) {
     return slots;
 }
 
-static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundles, int n_groups) {
+// n_rays: the rays of the frame being enqueued (the strides follow it); cap_rays >= n_rays: what the workspace must
+// hold without growing again (the largest part of a frame that is enqueued in parts).
+static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundles, int n_groups, uint32_t cap_rays_wanted = 0) {
     if (slots + 1 > sc->table_slots) { // one set of bundle tables per light in flight + one for the camera rays
         free_tables(sc);
         Tables &t = sc->tables;
@@ -3883,14 +3963,15 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
         sc->ev_resolve.push_back(e);
     }
     Work &w = sc->work;
-    if (n_rays <= sc->work_rays && slots <= sc->work_slots) {
+    cap_rays_wanted = std::max(cap_rays_wanted, n_rays);
+    if (cap_rays_wanted <= sc->work_rays && slots <= sc->work_slots) {
         // the slot strides follow the frame being rendered, not the capacity
         w.n = n_rays;
         w.tile_stride = n_rays / RAYS_PER_TILE + 1;
         w.list_stride = n_rays + RT_BINS / RT_PATCH * 64 * PACKET_RAYS_MAX;
         return RT355_OK;
     }
-    const uint32_t cap_rays = std::max(n_rays, sc->work_rays);
+    const uint32_t cap_rays = std::max(cap_rays_wanted, sc->work_rays);
     const int cap_slots = std::max(slots, sc->work_slots);
     free_work(sc);
     const size_t n = cap_rays, g = (size_t)cap_slots;
@@ -3988,7 +4069,7 @@ static int ensure_gather(rt355_scene *sc, size_t live_rows) {
 // A frame that one kernel renders can be enqueued as several calls, one per group of rows, that count into the
 // same statistics and are waited for as one: `first` clears the counters and uploads the lights, `last` closes
 // the frame (rt355_render reads every part back while the next one renders).
-struct PartOfFrame { bool first, last; };
+struct PartOfFrame { bool first, last; int max_rows = 0; }; // max_rows: the rows of the frame's largest part (0: this one)
 // How rt355_render takes a searched frame's pixels back while the frame is still being shaded: the last stage of the
 // frame (the shading of the last group of lights, the fold of the mirror levels, k_average) is launched in `n_parts`
 // parts of whole tile rows, and after each part `copy_rows(ya, yb)` is called for the local rows it completed in the
@@ -4043,7 +4124,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     f.deferred = 0;
     f.rid_base = 0; f.avg_row0 = 0;
     const int nl = shader->n_lights;
-    const int slots = slots_for(f.n_rays, nl);
+    // (a frame enqueued in parts sizes the workspace for its largest part at once: growing it between the parts would
+    // free memory that queued parts still use; all parts then group the lights alike)
+    const uint32_t cap_rays = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)f.tiles_x *
+                              (uint64_t)(((int64_t)std::max(part.max_rows, f.rows) * sub + TILE_H - 1) / TILE_H) * RAYS_PER_TILE);
+    const int slots = slots_for(cap_rays, nl);
     const int n_groups = (nl + slots - 1) / slots;
     // Mirror rays on a searched scene: the frame is rendered level by level.  A chain goes on while the product
     // of the ks it met is >= 0.05 and it has at most three mirror rays (main.cpp:27-28,103), so the largest |ks|
@@ -4077,7 +4162,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     } else {
         // search launches: the camera rays and two per group of lights, per level; the gather passes record two pairs
         const int n_search = std::max((1 + 2 * n_groups) * (1 + extra_levels), gather_searched ? 2 : 1);
-        rc = ensure_work(sc, f.n_rays, slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1);
+        rc = ensure_work(sc, f.n_rays, slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1, cap_rays);
         if (rc) return rc;
         if ((levels || gather_searched) && (rc = ensure_levels(sc))) return rc;
     }
@@ -4179,13 +4264,13 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     sc->launch_choice.clear();
     // rays per lane for a kind of launch: try 4, then 1, then keep the faster
     auto packet_rays_for = [&](int cls) -> int {
-        if (sc->forced_packet_rays) return sc->forced_packet_rays;
+        if (sc->knobs.packet_rays) return (int)sc->knobs.packet_rays;
         if (sc->tune_ms[cls][0] < 0) return 4;
         if (sc->tune_ms[cls][1] < 0) return 1;
         return sc->tune_ms[cls][0] <= sc->tune_ms[cls][1] ? 4 : 1;
     };
     // one search launch over the given slots (all of bundle kind `kind`); list / total = null for the camera rays
-    const int heavy_min_prims = getenv("RT355_HEAVY_MIN_PRIMS") ? atoi(getenv("RT355_HEAVY_MIN_PRIMS")) : HEAVY_MIN_PRIMS; // (tests: 0 = always)
+    const int heavy_min_prims = (int)sc->knobs.heavy_min_prims; // (tests: 0 = always)
     auto launch_search = [&](int kind, const Slots &sl, const uint32_t *list, const uint32_t *total,
                              uint32_t total_stride, bool spill_cleared = false) -> int {
         for (int i = 0; i < sl.count && !spill_cleared; i++) // empty spill lists for the bundles of this launch
@@ -4200,8 +4285,8 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             const dim3 grid_heavy(HEAVY_GRID, (unsigned)sl.count);
             const bool two_launches = sc->view.n_prims >= heavy_min_prims;
             Heavy hv = w.heavy;
-            hv.after = getenv("RT355_HEAVY_AFTER") ? (uint32_t)atoi(getenv("RT355_HEAVY_AFTER")) : HEAVY_AFTER; // (tests: hand over early)
-            hv.workers = getenv("RT355_HEAVY_WORKERS") ? (uint32_t)atoi(getenv("RT355_HEAVY_WORKERS")) : HEAVY_WORKERS;
+            hv.after = (uint32_t)sc->knobs.heavy_after; // (tests: hand over early)
+            hv.workers = (uint32_t)sc->knobs.heavy_workers;
             hv.workers = std::max<uint32_t>(PACKET_WAVES, hv.workers / PACKET_WAVES * PACKET_WAVES);
             if (two_launches) HIP_TRY(hipMemsetAsync(w.heavy.count, 0, LIGHT_GROUP * sizeof(uint32_t), st));
 #define PACKET_ARGS sc->tables, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride, hv
@@ -4305,7 +4390,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         const Gather ga{sc->d_dirs, sc->n_dirs};
         const SceneView &v = sc->view;
         const bool few = v.n_planes <= GATHER_FEW && v.n_spheres <= GATHER_FEW && v.n_planes + v.n_spheres == v.n_prims &&
-                         !getenv("RT355_GATHER_GENERAL");
+                         !sc->knobs.gather_general;
 #define LAUNCH_GATHER(B, F) hipLaunchKernelGGL((k_render_gather<B, F>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix)
         if (opts->shading == RT355_SHADING_BLEED) {
             if (few) LAUNCH_GATHER(true, GATHER_FEW); else LAUNCH_GATHER(true, 0);
@@ -4341,9 +4426,9 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
                                ? std::max(1, std::min(tail->n_parts, f.tiles_y)) : 1;
     bool tail_done = false;
     // the part of the last turn, whose transfer no kernel overlaps, is half as high as the others
-    const bool tail_top_first = !getenv("RT355_TAIL_BOTTOM_FIRST");
+    const bool tail_top_first = !sc->knobs.tail_bottom_first;
     auto tail_tile_row = [&](int p) {
-        if (tail_parts == 1 || getenv("RT355_TAIL_EVEN")) return (int)((int64_t)f.tiles_y * p / tail_parts);
+        if (tail_parts == 1 || sc->knobs.tail_even) return (int)((int64_t)f.tiles_y * p / tail_parts);
         const int64_t halves = 2 * tail_parts - 1;
         const int64_t before = tail_top_first ? std::max(0, 2 * p - 1) : std::min<int64_t>(2 * p, halves); // half-heights below part p
         return (int)(f.tiles_y * before / halves);
@@ -4475,8 +4560,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
         resolves = 1;
         const Gather ga{sc->d_dirs, sc->n_dirs};
-        int walk_blocks = 8192; // waves that stay, four to a workgroup: several times what the chip holds at once, so that the last ones even out
-        if (const char *e = getenv("RT355_WALK_BLOCKS")) walk_blocks = std::max(1, atoi(e));
+        const int walk_blocks = (int)sc->knobs.walk_blocks; // waves that stay, four to a workgroup: several times what the chip holds at once, so that the last ones even out
         if ((rc = ensure_gather(sc, (size_t)(sc->n_dirs + 63) / 64))) return rc; // (w refers to sc->work)
         hipLaunchKernelGGL(k_gather_init, dim3(per_ray_blocks), dim3(256), 0, st, f, w, ga);
         const bool bleed = opts->shading == RT355_SHADING_BLEED;
@@ -4515,17 +4599,22 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     return RT355_OK;
 }
 
+#define MULTI_HAS_NO(sc, what) \
+    if ((sc) && (sc)->multi) return fail(RT355_ERR_UNSUPPORTED, what ": a device pixmap lies on one GPU; a multi-device scene renders into host memory (rt355_render, rt355_render_sweep)")
 extern "C" int rt355_render_device(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                                    const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
+    MULTI_HAS_NO(sc, "rt355_render_device");
     return render_enqueue(sc, cam, shader, opts, d_pixmap, hip_stream, stats, false);
 }
 extern "C" int rt355_render_device_noalloc(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                                            const rt355_opts *opts, void *d_pixmap, void *hip_stream, rt355_stats *stats) {
+    MULTI_HAS_NO(sc, "rt355_render_device_noalloc");
     return render_enqueue(sc, cam, shader, opts, d_pixmap, hip_stream, stats, true);
 }
 
 extern "C" int rt355_scene_sync(rt355_scene *sc) {
     if (!sc) return fail(RT355_ERR_ARG, "rt355_scene_sync: null scene");
+    if (sc->multi) return RT355_OK; // (its calls return when the frame is in the caller's memory)
     if (!sc->pending) return RT355_OK;
     HIP_TRY(hipSetDevice(sc->device));
     HIP_TRY(hipEventSynchronize(sc->ev_done));
@@ -4595,6 +4684,7 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
 }
 
 extern "C" int rt355_scene_search_kernel_ms(rt355_scene *sc, double *ms_sum, int32_t *launches) {
+    if (sc && sc->multi) return rt355_scene_search_kernel_ms(sc->multi->scenes[0], ms_sum, launches); // (the first device's share)
     if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
     *ms_sum = sc->search_ms;
     *launches = sc->search_launches;
@@ -4603,6 +4693,7 @@ extern "C" int rt355_scene_search_kernel_ms(rt355_scene *sc, double *ms_sum, int
 
 
 extern "C" int rt355_scene_resolve_kernel_ms(rt355_scene *sc, double *ms_sum, int32_t *launches) {
+    if (sc && sc->multi) return rt355_scene_resolve_kernel_ms(sc->multi->scenes[0], ms_sum, launches); // (the first device's share)
     if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
     *ms_sum = sc->resolve_ms;
     *launches = sc->resolve_launches;
@@ -4610,12 +4701,14 @@ extern "C" int rt355_scene_resolve_kernel_ms(rt355_scene *sc, double *ms_sum, in
 }
 
 extern "C" int rt355_scene_resolve_launch_ms(rt355_scene *sc, int32_t index, double *ms) {
+    if (sc && sc->multi) return rt355_scene_resolve_launch_ms(sc->multi->scenes[0], index, ms); // (the first device's share)
     if (!sc || !ms || index < 0 || index >= (int32_t)sc->resolve_launch_ms.size()) return fail(RT355_ERR_ARG, "bad launch index");
     *ms = sc->resolve_launch_ms[index];
     return RT355_OK;
 }
 
 extern "C" int rt355_scene_search_launch_ms(rt355_scene *sc, int32_t index, double *ms) {
+    if (sc && sc->multi) return rt355_scene_search_launch_ms(sc->multi->scenes[0], index, ms); // (the first device's share)
     if (!sc || !ms || index < 0 || index >= (int32_t)sc->launch_ms.size()) return fail(RT355_ERR_ARG, "bad launch index");
     *ms = sc->launch_ms[index];
     return RT355_OK;
@@ -4624,8 +4717,9 @@ extern "C" int rt355_scene_search_launch_ms(rt355_scene *sc, int32_t index, doub
 // Page-locked host memory for the pixmap of rt355_render.
 extern "C" void *rt355_host_alloc(uint64_t bytes) {
     void *p = nullptr;
-    unsigned flags = hipHostMallocDefault;
-    if (const char *e = getenv("RT355_HOST_ALLOC_FLAGS")) flags = (unsigned)strtoul(e, nullptr, 0); // (experiments)
+    // page-locked for every GPU of the process and mapped into their address spaces: the GPUs of a multi-device scene
+    // all write their rows of a frame into the one pixmap
+    const unsigned flags = hipHostMallocPortable | hipHostMallocMapped;
     if (hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), flags) != hipSuccess) {
         (void)hipGetLastError();
         g_err = "rt355_host_alloc: hipHostMalloc failed";
@@ -4636,7 +4730,7 @@ extern "C" void *rt355_host_alloc(uint64_t bytes) {
 extern "C" void rt355_host_free(void *p) { if (p) (void)hipHostFree(p); }
 extern "C" int rt355_host_register(void *p, uint64_t bytes) {
     if (!p || !bytes) return fail(RT355_ERR_ARG, "rt355_host_register: null pointer or no bytes");
-    HIP_TRY(hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped));
+    HIP_TRY(hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped));
     return RT355_OK;
 }
 extern "C" int rt355_host_unregister(void *p) {
@@ -4669,7 +4763,7 @@ static int ensure_readback(rt355_scene *sc) {
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         sc->ev_part.push_back(e);
     }
-    if (first_call && !getenv("RT355_NO_COPY_PRIME") && sc->fb) {
+    if (first_call && !sc->knobs.no_copy_prime && sc->fb) {
         // The runtime grows what it keeps per transfer in flight the first time a process has had some dozens of them
         // (one call of 6 ms somewhere among a handle's first ten frames, measured); a burst of small transfers between
         // events, as a frame's parts make them, has that happen here, in the call that sets the handle up anyway.
@@ -4679,7 +4773,7 @@ static int ensure_readback(rt355_scene *sc) {
             hipStream_t cs = (i & 1) ? sc->copy_stream2 : sc->copy_stream;
             HIP_TRY(hipEventRecord(sc->ev_part[i % RENDER_PARTS_MAX], nullptr));
             HIP_TRY(hipStreamWaitEvent(cs, sc->ev_part[i % RENDER_PARTS_MAX], 0));
-            HIP_TRY(hipMemcpyAsync(sc->host_counters, sc->fb, 64, hipMemcpyDeviceToHost, cs));
+            HIP_TRY(hipMemcpyAsync(sc->host_counters, sc->fb, std::min<size_t>(64, sc->fb_bytes), hipMemcpyDeviceToHost, cs));
             HIP_TRY(hipEventRecord(sc->ev_copy[i % RENDER_PARTS_MAX], cs));
         }
         HIP_TRY(hipStreamSynchronize(sc->copy_stream));
@@ -4698,6 +4792,7 @@ static int ensure_readback(rt355_scene *sc) {
 extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader,
                             const rt355_opts *opts, unsigned char *pixmap, rt355_stats *stats) {
     if (!sc || !opts || !pixmap) return fail(RT355_ERR_ARG, "rt355_render: null argument");
+    if (sc->multi) return multi_render(sc, cam, shader, opts, pixmap, stats);
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
     const auto t_call = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(sc->device));
@@ -4715,7 +4810,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
     const bool one_kernel = opts->tile_count <= 1 && !searched;
     // a searched frame whose last stage can be launched in parts, each read back while the next is shaded (TailParts)
-    const bool tail_way = searched && opts->tile_count <= 1 && opts->alias == 0 && !getenv("RT355_NO_TAIL_PARTS") &&
+    const bool tail_way = searched && opts->tile_count <= 1 && opts->alias == 0 && !sc->knobs.no_tail_parts &&
                           (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
     // A page-locked pixmap is mapped into the device's address space, and the kernels that write the pixels can
     // write them there, whole dwords in row order: the transfer over PCIe then runs while the frame is rendered
@@ -4732,7 +4827,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // show what those cost back to back --, the frames after them go the way whose shortest of its last three calls
     // was shorter, and every READBACK_RETRY-th frame the other way once more
     // (what the link to the host gives changes while a process runs).  The event the call waits on orders the
-    // writes before the caller's reads.  (RT355_READBACK_COPY / RT355_READBACK_DIRECT force one way.)
+    // writes before the caller's reads.  (The handle's option "readback" forces one way: rt355_scene_set_option.)
     bool direct = pinned, timing = false;
     if (pinned && (one_kernel || tail_way)) {
         uint64_t key = 0x9e3779b97f4a7c15ull;
@@ -4751,8 +4846,8 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         else direct = (sc->readback_frames % READBACK_RETRY == 0) ? !faster_direct : faster_direct;
         timing = true;
     }
-    if (getenv("RT355_READBACK_COPY")) { direct = false; timing = false; }
-    if (getenv("RT355_READBACK_DIRECT")) { direct = pinned; timing = false; }
+    if (sc->knobs.readback == 2) { direct = false; timing = false; }
+    if (sc->knobs.readback == 1) { direct = pinned; timing = false; }
     auto timed = [&](int rc) { // a call has ended
         if (!timing) return rc;
         if (rc != RT355_OK) { sc->readback_key = 0; return rc; }
@@ -4785,8 +4880,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // and only its last stage comes in parts (tail_way below)
     int n_parts = 1;
     if (one_kernel) {
-        n_parts = 6;
-        if (const char *e = getenv("RT355_RENDER_PARTS")) n_parts = atoi(e);
+        n_parts = (int)sc->knobs.render_parts;
         n_parts = std::max(1, std::min(n_parts, std::min(RENDER_PARTS_MAX, (rows.y1 - rows.y0) / 128)));
     }
     int part_y0[RENDER_PARTS_MAX + 1];
@@ -4799,8 +4893,8 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     // the rows a part (or a share's tiles) covers go back as one transfer each, once the part has been rendered
     // the transfers alternate between two streams, so that one's set-up hides behind the other's data, and the last
     // part, which no later kernel would overlap, is written straight into a page-locked pixmap
-    const bool two_streams = !(getenv("RT355_COPY_STREAMS") && atoi(getenv("RT355_COPY_STREAMS")) == 1);
-    const bool last_direct = pinned && !getenv("RT355_LAST_COPIED");
+    const bool two_streams = sc->knobs.copy_streams != 1;
+    const bool last_direct = pinned && !sc->knobs.last_copied;
     auto read_back = [&](int ya, int yb, hipEvent_t rendered, hipEvent_t done, hipStream_t copy_stream) -> int {
         HIP_TRY(hipEventRecord(rendered, nullptr));
         HIP_TRY(hipStreamWaitEvent(copy_stream, rendered, 0));
@@ -4832,8 +4926,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     int copy_ya[RENDER_PARTS_MAX], copy_yb[RENDER_PARTS_MAX]; // ... and their rows
     if (tail_way) { // one enqueue; its last stage comes in parts, and each part's rows are read back as it completes
         TailParts tp;
-        tp.n_parts = 4;
-        if (const char *e = getenv("RT355_TAIL_PARTS")) tp.n_parts = atoi(e);
+        tp.n_parts = (int)sc->knobs.tail_parts;
         tp.n_parts = std::max(1, std::min(tp.n_parts, RENDER_PARTS_MAX));
         void *mapped = nullptr;
         if (!(last_direct && tp.n_parts > 1 && hipHostGetDevicePointer(&mapped, pixmap, 0) == hipSuccess && mapped)) {
@@ -4852,15 +4945,17 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
         rc = render_enqueue(sc, cam, shader, opts, sc->fb, nullptr, stats, false, PartOfFrame{true, true}, &tp);
         n_parts = 0;
     }
+    int max_part_rows = 0;
+    for (int i = 0; i < n_parts; i++) max_part_rows = std::max(max_part_rows, part_y0[i + 1] - part_y0[i]);
     for (int i = 0; i < n_parts && rc == RT355_OK; i++) {
         rt355_opts part = *opts;
         part.row_begin = part_y0[i]; part.row_end = part_y0[i + 1];
         void *mapped = nullptr;
         if (last_direct && i == n_parts - 1 && n_parts > 1 && hipHostGetDevicePointer(&mapped, pixmap, 0) == hipSuccess && mapped) {
-            rc = render_enqueue(sc, cam, shader, &part, mapped, nullptr, stats, false, PartOfFrame{false, true});
+            rc = render_enqueue(sc, cam, shader, &part, mapped, nullptr, stats, false, PartOfFrame{false, true, max_part_rows});
             continue;
         }
-        rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, stats, false, PartOfFrame{i == 0, i == n_parts - 1});
+        rc = render_enqueue(sc, cam, shader, &part, sc->fb, nullptr, stats, false, PartOfFrame{i == 0, i == n_parts - 1, max_part_rows});
         if (rc == RT355_OK) rc = read_back(part_y0[i], part_y0[i + 1], sc->ev_part[i], sc->ev_copy[i], (two_streams && (i & 1)) ? sc->copy_stream2 : sc->copy_stream);
         if (rc == RT355_OK) { copy_ya[i] = part_y0[i]; copy_yb[i] = part_y0[i + 1]; n_copies = i + 1; }
     }
@@ -4888,6 +4983,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
 extern "C" int rt355_render_sweep(rt355_scene *sc, const rt355_camera *cams, int32_t n_frames, const rt355_shader *shader,
                                   const rt355_opts *opts, unsigned char *const *pixmaps, rt355_stats *stats) {
     if (!sc || !opts || n_frames < 0 || (n_frames && (!cams || !pixmaps))) return fail(RT355_ERR_ARG, "rt355_render_sweep: bad argument");
+    if (sc->multi) return multi_sweep(sc, cams, n_frames, shader, opts, pixmaps, stats);
     if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
     for (int i = 0; i < n_frames; i++)
         if (!pixmaps[i]) return fail(RT355_ERR_ARG, "rt355_render_sweep: null pixmap");
@@ -4965,8 +5061,229 @@ extern "C" int rt355_render_sweep(rt355_scene *sc, const rt355_camera *cams, int
     return rc;
 }
 
+
+// =====================================================================================================
+// One scene on several GPUs of this process (rt355_scene_create_multi)
+// =====================================================================================================
+// The handle holds one ordinary scene per device and a host thread per scene (the render calls block, and a thread's
+// current device is its own).  rt355_render deals the 32-row tiles of the caller's slab to the scenes, share i to
+// scene i, every GPU writing its rows over its own link into the caller's one pixmap (kernels' own stores for a
+// page-locked pixmap, each scene's staging memory and a host copy for a pageable one); rt355_render_sweep deals whole
+// frames, frame f to scene f mod N.  With the option "gather" = 1 the shares are rendered into HBM, copied to the
+// first device's framebuffer over the GPUs' own links (hipMemcpyPeerAsync) and read back from there in one transfer.
+static void multi_worker_main(MultiWorker *w, int device) {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lock(w->m);
+    for (;;) {
+        w->cv.wait(lock, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has_job = false;
+        lock.unlock();
+        g_err.clear();
+        const int rc = job();
+        lock.lock();
+        w->rc = rc;
+        w->err = g_err; // (the message of a failed call is the worker thread's own: carried back to the caller's)
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+// fn(i) on scene i's thread, all at once; the first failure's code and message
+static int multi_run(MultiScene &m, const std::function<int(int)> &fn) {
+    const int n = (int)m.scenes.size();
+    for (int i = 0; i < n; i++) {
+        MultiWorker &w = *m.workers[i];
+        std::lock_guard<std::mutex> lock(w.m);
+        w.job = [i, &fn] { return fn(i); };
+        w.has_job = true; w.done = false;
+        w.cv.notify_all();
+    }
+    int rc = RT355_OK;
+    std::string why;
+    for (int i = 0; i < n; i++) {
+        MultiWorker &w = *m.workers[i];
+        std::unique_lock<std::mutex> lock(w.m);
+        w.cv.wait(lock, [&] { return w.done; });
+        if (w.rc != RT355_OK && rc == RT355_OK) { rc = w.rc; why = "device " + std::to_string(m.devices[i]) + ": " + w.err; }
+    }
+    if (rc != RT355_OK) g_err = why;
+    return rc;
+}
+static void multi_destroy(rt355_scene *sc) {
+    MultiScene *m = sc->multi;
+    for (auto &w : m->workers) {
+        { std::lock_guard<std::mutex> lock(w->m); w->quit = true; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
+    }
+    for (rt355_scene *r : m->scenes) rt355_scene_destroy(r);
+    delete m;
+    delete sc;
+}
+static void multi_sum(const std::vector<rt355_stats> &st, rt355_stats *out) {
+    if (!out) return;
+    memset(out, 0, sizeof *out);
+    for (const rt355_stats &s : st) {
+        out->primary_rays += s.primary_rays; out->shadow_rays += s.shadow_rays; out->pair_tests += s.pair_tests;
+        out->exact_tests += s.exact_tests; out->overflow_rays += s.overflow_rays; out->packet_survivors += s.packet_survivors;
+        out->primary_hits += s.primary_hits; out->secondary_rays += s.secondary_rays; out->gather_rays += s.gather_rays;
+        out->ms_device = std::max(out->ms_device, s.ms_device); // the GPUs work side by side: the longest
+    }
+}
+
+extern "C" int rt355_scene_create_multi(const rt355_scene_desc *d, const int32_t *devices, int32_t n_devices, rt355_scene **out) {
+    if (!d || !out || !devices || n_devices < 1 || n_devices > MULTI_MAX_DEVICES)
+        return fail(RT355_ERR_ARG, "rt355_scene_create_multi: null argument, or not 1.." + std::to_string(MULTI_MAX_DEVICES) + " devices");
+    int have = 0, before = 0;
+    HIP_TRY(hipGetDeviceCount(&have));
+    HIP_TRY(hipGetDevice(&before));
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= have)
+            return fail(RT355_ERR_ARG, "rt355_scene_create_multi: device " + std::to_string(devices[i]) + " of " + std::to_string(have));
+    rt355_scene *sc = new rt355_scene();
+    sc->multi = new MultiScene();
+    sc->device = devices[0];
+    int rc = RT355_OK;
+    for (int i = 0; i < n_devices && rc == RT355_OK; i++) { // the scene replicated: flattened and uploaded once per device
+        if (hipSetDevice(devices[i]) != hipSuccess) { (void)hipGetLastError(); rc = fail(RT355_ERR_DEVICE, "hipSetDevice failed"); break; }
+        rt355_scene *r = nullptr;
+        rc = rt355_scene_create(d, &r);
+        if (rc == RT355_OK) { sc->multi->scenes.push_back(r); sc->multi->devices.push_back(devices[i]); }
+    }
+    (void)hipSetDevice(before);
+    if (rc != RT355_OK) {
+        const std::string why = g_err;
+        multi_destroy(sc);
+        g_err = why;
+        return rc;
+    }
+    for (int i = 0; i < n_devices; i++) {
+        sc->multi->workers.emplace_back(new MultiWorker());
+        MultiWorker *w = sc->multi->workers.back().get();
+        w->th = std::thread(multi_worker_main, w, devices[i]);
+    }
+    *out = sc;
+    return RT355_OK;
+}
+
+static int ensure_fb(rt355_scene *r, size_t bytes) {
+    if (bytes <= r->fb_bytes) return RT355_OK;
+    if (r->fb) { (void)hipFree(r->fb); r->fb = nullptr; r->fb_bytes = 0; }
+    HIP_TRY(hipMalloc((void **)&r->fb, bytes));
+    r->fb_bytes = bytes;
+    return RT355_OK;
+}
+
+static int multi_render(rt355_scene *sc, const rt355_camera *cam, const rt355_shader *shader, const rt355_opts *opts,
+                        unsigned char *pixmap, rt355_stats *stats) {
+    MultiScene &m = *sc->multi;
+    const int n = (int)m.scenes.size();
+    if (!cam || !shader || !opts || !pixmap) return fail(RT355_ERR_ARG, "rt355_render: null argument");
+    if (opts->width <= 0 || opts->height <= 0) return fail(RT355_ERR_ARG, "width and height must be positive");
+    if (opts->tile_count > 1)
+        return fail(RT355_ERR_UNSUPPORTED, "rt355_render on a multi-device scene deals the row tiles itself: leave tile_count at 0");
+    Rows rows;
+    { int rc0 = rows_of(opts, &rows); if (rc0) return rc0; }
+    std::vector<rt355_stats> st((size_t)n);
+    for (auto &s : st) memset(&s, 0, sizeof s);
+    auto share_of = [&](int i) {
+        rt355_opts o = *opts;
+        o.tile_rows = MULTI_TILE_ROWS; o.tile_count = n; o.tile_phase = i;
+        return o;
+    };
+    int rc;
+    if (m.gather == 0 || n == 1) {
+        rc = multi_run(m, [&](int i) {
+            const rt355_opts o = share_of(i);
+            return rt355_render(m.scenes[i], cam, shader, n == 1 ? opts : &o, pixmap, &st[i]);
+        });
+    } else {
+        const size_t row_bytes = (size_t)opts->width * 3, bytes = row_bytes * (size_t)opts->height;
+        rc = multi_run(m, [&](int i) { // every share into its own GPU's framebuffer
+            rt355_scene *r = m.scenes[i];
+            HIP_TRY(hipSetDevice(r->device));
+            int rc1 = ensure_fb(r, bytes);
+            if (rc1) return rc1;
+            const rt355_opts o = share_of(i);
+            if ((rc1 = render_enqueue(r, cam, shader, &o, r->fb, nullptr, &st[i], false))) return rc1;
+            return rt355_scene_sync(r);
+        });
+        if (rc == RT355_OK)
+            rc = multi_run(m, [&](int i) { // ... its rows to the first GPU over the link between the two
+                if (i == 0) return (int)RT355_OK;
+                rt355_scene *r = m.scenes[i], *r0 = m.scenes[0];
+                HIP_TRY(hipSetDevice(r->device));
+                if (r->device != r0->device) { // (direct access where the devices allow it; the copy works without)
+                    const hipError_t e = hipDeviceEnablePeerAccess(r0->device, 0);
+                    if (e != hipSuccess) (void)hipGetLastError();
+                }
+                for (int k = i; k * MULTI_TILE_ROWS < rows.y1 - rows.y0; k += n) {
+                    const int ta = rows.y0 + k * MULTI_TILE_ROWS, tb = std::min(rows.y1, ta + MULTI_TILE_ROWS);
+                    HIP_TRY(hipMemcpyPeerAsync(r0->fb + ta * row_bytes, r0->device, r->fb + ta * row_bytes, r->device,
+                                               (size_t)(tb - ta) * row_bytes, nullptr));
+                }
+                HIP_TRY(hipStreamSynchronize(nullptr));
+                return (int)RT355_OK;
+            });
+        if (rc == RT355_OK)
+            rc = multi_run(m, [&](int i) { // ... and the frame's rows from there to the caller, one transfer
+                if (i != 0) return (int)RT355_OK;
+                rt355_scene *r0 = m.scenes[0];
+                HIP_TRY(hipSetDevice(r0->device));
+                HIP_TRY(hipMemcpy(pixmap + rows.y0 * row_bytes, r0->fb + rows.y0 * row_bytes, (size_t)(rows.y1 - rows.y0) * row_bytes, hipMemcpyDeviceToHost));
+                return (int)RT355_OK;
+            });
+    }
+    if (rc == RT355_OK) multi_sum(st, stats);
+    return rc;
+}
+
+static int multi_sweep(rt355_scene *sc, const rt355_camera *cams, int32_t n_frames, const rt355_shader *shader,
+                       const rt355_opts *opts, unsigned char *const *pixmaps, rt355_stats *stats) {
+    MultiScene &m = *sc->multi;
+    const int n = (int)m.scenes.size();
+    if (!opts || n_frames < 0 || (n_frames && (!cams || !pixmaps))) return fail(RT355_ERR_ARG, "rt355_render_sweep: bad argument");
+    // frame f on scene f mod N: each scene sweeps its frames through its own framebuffers and copy stream
+    std::vector<std::vector<rt355_camera>> my_cams((size_t)n);
+    std::vector<std::vector<unsigned char *>> my_pix((size_t)n);
+    std::vector<std::vector<rt355_stats>> my_st((size_t)n);
+    for (int f = 0; f < n_frames; f++) {
+        my_cams[f % n].push_back(cams[f]);
+        my_pix[f % n].push_back(pixmaps[f]);
+    }
+    for (int i = 0; i < n; i++) my_st[i].resize(my_cams[i].size());
+    const int rc = multi_run(m, [&](int i) {
+        if (my_cams[i].empty()) return (int)RT355_OK;
+        return rt355_render_sweep(m.scenes[i], my_cams[i].data(), (int32_t)my_cams[i].size(), shader, opts, my_pix[i].data(), my_st[i].data());
+    });
+    for (int f = 0; f < n_frames && stats && rc == RT355_OK; f++) stats[f] = my_st[f % n][f / n];
+    return rc;
+}
+
+extern "C" int rt355_scene_set_option(rt355_scene *sc, const char *name, int64_t value) {
+    if (!sc || !name) return fail(RT355_ERR_ARG, "rt355_scene_set_option: null argument");
+    if (sc->multi) {
+        if (!strcmp(name, "gather")) {
+            if (value != 0 && value != 1) return fail(RT355_ERR_ARG, "option gather: 0 (rows into the host pixmap) or 1 (rows to the first GPU)");
+            sc->multi->gather = (int)value;
+            return RT355_OK;
+        }
+        for (rt355_scene *r : sc->multi->scenes) { const int rc = rt355_scene_set_option(r, name, value); if (rc) return rc; }
+        return RT355_OK;
+    }
+    if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
+    const int rc = set_knob(sc->knobs, name, value);
+    if (rc == RT355_OK && !strcmp(name, "readback")) sc->readback_key = 0; // (what was timed so far decides nothing any more)
+    if (rc == RT355_OK && !strcmp(name, "debug_readback") && value) sc->debug_series.reserve(4096);
+    return rc;
+}
+
 extern "C" int rt355_scene_set_directions(rt355_scene *sc, const double *xyz, int32_t n) {
     if (!sc || n < 0 || (n && !xyz)) return fail(RT355_ERR_ARG, "rt355_scene_set_directions: bad argument");
+    if (sc->multi) {
+        for (rt355_scene *r : sc->multi->scenes) { const int rc = rt355_scene_set_directions(r, xyz, n); if (rc) return rc; }
+        return RT355_OK;
+    }
     HIP_TRY(hipSetDevice(sc->device));
     if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     if (sc->d_dirs) { (void)hipFree(sc->d_dirs); sc->d_dirs = nullptr; }
@@ -5010,6 +5327,7 @@ extern "C" int rt355_probe_sincos(const double *x, int n, double *out) {
 // Debug probe: objs[obj]->CalcIntersect for n host rays (n x 6 doubles) -> n x 9 doubles
 // (t, ph, nh, uv).  Lets the fp64 device formulas be checked in isolation.
 extern "C" int rt355_probe_intersect(rt355_scene *sc, int obj, const double *rays, int n, double *out) {
+    if (sc && sc->multi) return rt355_probe_intersect(sc->multi->scenes[0], obj, rays, n, out);
     if (!sc || !rays || !out || n <= 0 || obj < 0 || obj >= sc->view.n_objects) return fail(RT355_ERR_ARG, "rt355_probe_intersect: bad argument");
     HIP_TRY(hipSetDevice(sc->device));
     double *dr = nullptr, *dout = nullptr;

@@ -49,6 +49,14 @@ def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_frames, world))
 
 
+def host_barrier(dist):
+    """A barrier over host memory (an all-reduce of one CPU number): with the control plane on gloo it involves no GPU
+    collective, whatever backend moves GPU tensors."""
+    import torch
+    t = torch.zeros(1, dtype=torch.float64)
+    dist.all_reduce(t)
+
+
 class SharedPixmap:
     """One (height, width, 3) uint8 pixmap in host memory shared by every rank of the job (a file in /dev/shm that
     all of them map), page-locked by each rank for its own GPU where the runtime allows it: rank r's rt355_render writes r's rows of the frame
@@ -62,26 +70,34 @@ class SharedPixmap:
         import numpy as np
         n = width * height * 3
         name = [None]
-        if rank == 0:
-            name[0] = f"/dev/shm/rt355_pixmap_{os.getpid()}_{id(self):x}"
-            with open(name[0], "wb") as f:
-                f.truncate(n)
-        if world > 1:
-            dist.broadcast_object_list(name, src=0)
-        fd = os.open(name[0], os.O_RDWR)
-        try:
-            self._map = mmap.mmap(fd, n)
-        finally:
-            os.close(fd)
-        if world > 1:
-            dist.barrier()  # every rank has mapped it: the name can go
-        if rank == 0:
-            os.unlink(name[0])
-        self.array = np.frombuffer(self._map, dtype=np.uint8).reshape(height, width, 3)
-        # (the HIP runtime of this image refuses to page-lock a mapping that a file backs -- /dev/shm and memfd
-        # alike --: the pixmap then stays pageable, and rt355_render passes a rank's rows through the handle's own
-        # page-locked staging memory, part by part as they arrive)
+        self.array = None
         self.registered = False
+        try:
+            if rank == 0:
+                name[0] = f"/dev/shm/rt355_pixmap_{os.getpid()}_{id(self):x}"
+                with open(name[0], "wb") as f:
+                    f.truncate(n)
+            if world > 1:
+                import torch
+                dist.broadcast_object_list(name, src=0, device=torch.device("cpu"))
+            fd = os.open(name[0], os.O_RDWR)
+            try:
+                self._map = mmap.mmap(fd, n)
+            finally:
+                os.close(fd)
+            if world > 1:
+                host_barrier(dist)  # every rank has mapped it: the name can go
+        finally:
+            # whatever happened on the way (a rank that failed leaves the others in the collective until the launcher
+            # ends them), the file's name does not outlive this constructor on rank 0
+            if rank == 0 and name[0] and os.path.exists(name[0]):
+                os.unlink(name[0])
+        self.array = np.frombuffer(self._map, dtype=np.uint8).reshape(height, width, 3)
+        # The HIP runtime of this image refuses to page-lock a mapping that a file backs (/dev/shm and memfd alike):
+        # `registered` is then False, the pixmap stays pageable, and rt355_render passes a rank's rows through the
+        # handle's own page-locked staging memory and a host copy, part by part as they arrive.  The registered
+        # direct-write path across processes has therefore never run here; one process driving several GPUs
+        # (rt355_scene_create_multi) has every GPU write into one page-locked pixmap without any of this.
         if register:
             from .api import lib
             self.registered = lib().rt355_host_register(self.array.ctypes.data, n) == 0
@@ -99,12 +115,13 @@ class SharedPixmap:
                 pass
 
 
-def gather_frame(local_frame, rank: int, world: int, dst: int = 0, shard: str = "slabs", tile_rows: int = TILE_ROWS):
+def gather_frame(local_frame, rank: int, world: int, dst: int = 0, shard: str = "slabs", tile_rows: int = TILE_ROWS, group=None):
     """Assemble the final frame on `dst` from every rank's rows.
 
     local_frame: a (H, W, 3) uint8 torch tensor whose rows rows_of(H, world, rank, shard) are valid.
     Returns the full (H, W, 3) tensor on `dst`, None elsewhere.  Every rank sends its rows packed
-    together, padded to the largest share so that one gather with equal-sized buffers suffices.
+    together, padded to the largest share so that one gather with equal-sized buffers suffices.  `group`: the process
+    group that carries the rows (an RCCL group for rows in HBM; None = the default group).
     """
     import torch
     import torch.distributed as dist
@@ -115,7 +132,7 @@ def gather_frame(local_frame, rank: int, world: int, dst: int = 0, shard: str = 
     shares = [rows_of(H, world, r, shard, tile_rows) for r in range(world)]
     pad = max(sum(e - b for b, e in s) for s in shares)
     # gloo moves host memory: with that backend rows on the GPU are staged through the host (RCCL takes them as they are)
-    via_host = local_frame.is_cuda and dist.get_backend() == "gloo"
+    via_host = local_frame.is_cuda and dist.get_backend(group) == "gloo"
     send = torch.zeros((pad,) + tuple(local_frame.shape[1:]), dtype=local_frame.dtype,
                        device="cpu" if via_host else local_frame.device)
     at = 0
@@ -123,7 +140,7 @@ def gather_frame(local_frame, rank: int, world: int, dst: int = 0, shard: str = 
         send[at: at + e - b].copy_(local_frame[b:e])
         at += e - b
     bufs = [torch.zeros_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst)
+    dist.gather(send, bufs, dst=dst, group=group)
     if rank != dst:
         return None
     out = torch.empty_like(local_frame)

@@ -186,7 +186,7 @@ def test_sweep_entry_point(api):
         r.close()
 
 
-def test_search_in_two_launches(api, oracle, monkeypatch):
+def test_search_in_two_launches(api, oracle):
     """The packet search of a large scene runs as two launches: a wave that has met enough primitives hands the rest
     of its walk to many waves, which append to its rays' lists through the rays' counts in memory.  Forced here on
     small scenes, with waves handing over after 4 and after 64 primitives (and a list of candidates that overflows
@@ -206,11 +206,11 @@ def test_search_in_two_launches(api, oracle, monkeypatch):
         allp, ast = r.render(cam, sh, w, h, mode=B.MODE_ALLPAIRS)
         assert np.array_equal(one, want) and np.array_equal(allp, want)
         for after in ("4", "64"):
-            monkeypatch.setenv("RT355_HEAVY_MIN_PRIMS", "0")
-            monkeypatch.setenv("RT355_HEAVY_AFTER", after)
+            r.set_option("heavy_min_prims", 0)
+            r.set_option("heavy_after", int(after))
             two, tst = r.render(cam, sh, w, h)
-            monkeypatch.delenv("RT355_HEAVY_MIN_PRIMS")
-            monkeypatch.delenv("RT355_HEAVY_AFTER")
+            r.set_option("heavy_min_prims", 300000)
+            r.set_option("heavy_after", 256)
             assert np.array_equal(two, want), (name, after)
             for k in ("shadow_rays", "exact_tests", "overflow_rays", "secondary_rays"):
                 assert tst[k] == ost[k] == ast[k], (name, after, k)

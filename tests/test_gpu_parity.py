@@ -187,14 +187,14 @@ def test_more_lights_than_one_group(api, oracle, n_lights):
 
 
 @pytest.mark.parametrize("rays_per_lane", ["1", "4"])
-def test_packet_sizes_give_the_same_frames(api, oracle, monkeypatch, rays_per_lane):
+def test_packet_sizes_give_the_same_frames(api, oracle, rays_per_lane):
     """The packet search exists with 64-ray and 256-ray waves; a scene handle normally times both and keeps
     the faster one.  Pinned to either, frames and candidate counts must not change."""
-    monkeypatch.setenv("RT355_PACKET_RAYS", rays_per_lane)
     for name in ("spheres300", "spheres300_dir", "mesh", "mesh_dir", "textured"):
         sc, sh, cam, w, h = S.small_case(name)
         want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h), threads=0)
         r = api.Renderer(sc)
+        r.set_option("packet_rays", int(rays_per_lane))
         got, st = r.render(cam, sh, w, h, mode=B.MODE_PACKET)
         ref, rst = r.render(cam, sh, w, h, mode=B.MODE_ALLPAIRS)
         r.close()
@@ -887,7 +887,7 @@ def test_gather_shaders_vs_golden_and_checker(api, oracle, golden_dir):
 
 
 @pytest.mark.gpu
-def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle, monkeypatch):
+def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle):
     """A scene of a few objects renders the gather shaders in every mode (nothing is searched), slab by slab
     as well; no direction set gives black hits, on a searched scene too."""
     sc, sh, cam, w, h = S.small_case("default_2lights")
@@ -906,14 +906,12 @@ def test_gather_small_scene_needs_no_mode_and_rows_shard(api, oracle, monkeypatc
     assert np.array_equal(parts, want)
     # a scene of at most four planes and four spheres takes the kernel that keeps the objects' origin terms in
     # registers; the general kernel gives the same frame
-    monkeypatch.setenv("RT355_GATHER_GENERAL", "1")
     for shading in (B.SHADING_BLEED, B.SHADING_OCCLUSION):
+        r.set_option("gather_general", 1)
         general, gst = r.render(cam, sh, w, h, seed=3, shading=shading)
-        monkeypatch.delenv("RT355_GATHER_GENERAL")
+        r.set_option("gather_general", 0)
         few, fst = r.render(cam, sh, w, h, seed=3, shading=shading)
-        monkeypatch.setenv("RT355_GATHER_GENERAL", "1")
         assert np.array_equal(general, few) and gst["gather_rays"] == fst["gather_rays"]
-    monkeypatch.delenv("RT355_GATHER_GENERAL")
     r.close()
     big, bsh, bcam, bw, bh = S.small_case("spheres300")
     r = api.Renderer(big)

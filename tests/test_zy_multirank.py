@@ -20,11 +20,11 @@ def _bench(*args):
     p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "3", "--warmup", "2"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        out, err = p.communicate(timeout=240)
+        out, err = p.communicate(timeout=420)
     except subprocess.TimeoutExpired:
         os.killpg(p.pid, signal.SIGKILL)
         out, err = p.communicate()
-        pytest.fail("bench.py " + " ".join(args) + " did not end in 240 s:\n" + err[-2000:])
+        pytest.fail("bench.py " + " ".join(args) + " did not end in 420 s:\n" + err[-2000:])
     assert p.returncode == 0, err[-2000:]
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out[-2000:]  # rank 0 prints ONE line
@@ -32,8 +32,16 @@ def _bench(*args):
 
 
 def test_two_ranks_whole_frames():
-    one = _bench("--gpus", "1", "--no-others", "--no-allpairs", "--no-cpu-baseline")
+    one = _bench("--gpus", "1", "--no-others", "--no-scaling", "--no-allpairs", "--no-cpu-baseline")
     two = _bench("--gpus", "2")
+    # the headline keeps its roofline and CPU baseline at N > 1 (rank 0's, for frames it rendered whole)
+    assert two["roofline"]["frac"] > 0 and two["cpu_baseline"]["value"] > 0 and two["cpu_baseline"]["parity_sample"] == "ok"
+    # the plain `--gpus N` run measures the scaling workloads: the 8K and 4K frames in tiles between the ranks, the sweep
+    sw = two["scaling_workloads"]
+    assert set(sw) == {"mesh1m_8k_tiles", "spheres10k_tiles", "mesh100k_sweep60"}
+    for name in ("mesh1m_8k_tiles", "spheres10k_tiles"):
+        assert sw[name]["gathered_frame"] == "ok" and sw[name]["scaling"] == "strong" and sw[name]["shard"] == "tiles"
+    assert all(v["ms"] > 0 and v["value"] > 0 for v in sw.values())
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["workload"] == one["config"]["workload"]
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
     # value counts the rays of both ranks over the slower rank's time
@@ -55,4 +63,4 @@ def test_two_ranks_share_a_frame(shard, gather):
 
 def test_two_ranks_sweep():
     d = _bench("--gpus", "2", "--workload", "mesh100k_sweep60")
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 60 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 60 and d["value"] > 0 and d["scaling"] == "strong"

@@ -52,6 +52,35 @@ def test_noalloc_equals_render_device_two_calls_in_a_row(api):
     r.close()
 
 
+def test_noalloc_first_render_of_a_fresh_handle_allocates_nothing(api):
+    """A handle whose first render is the no-alloc entry point (everything it needs was made by rt355_scene_create), with
+    the device's free memory read before the call and after its sync: unchanged.  Bytes against another handle's
+    rt355_render_device."""
+    import torch
+    sc, sh, _, _, _ = S.small_case("default_2lights")
+    w, h = 192, 128
+    cam, o = S.default_camera(w, h), B.opts(w, h, alias=2, seed=4)
+    stream = torch.cuda.current_stream().cuda_stream
+    fb = torch.full((h, w, 3), 77, dtype=torch.uint8, device="cuda")
+    fresh = api.Renderer(sc)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    fresh.render_device_noalloc(cam, sh, o, fb.data_ptr(), stream)
+    gst = fresh.sync()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before, (free_before, free_after)
+    got = fb.cpu().numpy()
+    other = api.Renderer(sc)
+    fb2 = torch.full((h, w, 3), 78, dtype=torch.uint8, device="cuda")
+    other.render_device(cam, sh, o, fb2.data_ptr(), stream)
+    wst = other.sync()
+    assert np.array_equal(got, fb2.cpu().numpy())
+    for k in KEYS:
+        assert gst[k] == wst[k], k
+    fresh.close()
+    other.close()
+
+
 @pytest.mark.parametrize("name", ["mirrors", "glass", "quadrics", "environment", "textured", "no_lights", "empty_scene"])
 def test_noalloc_every_unsearched_renderer(api, name):
     sc, sh, cam, w, h = S.small_case(name)

@@ -11,7 +11,7 @@ export RT355_READBACK_COPY=1 RT355_RENDER_PARTS=1 RT355_TAIL_PARTS=1
 for wl in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     tag=traffic_${wl}_$c
-    timeout -s KILL 150 rocprofv3 --pmc $c -d gpurun_out/$tag -- python3 bench.py --steps 3 --warmup 1 --workload $wl --no-others --no-allpairs --no-cpu-baseline > gpurun_out/$tag.log 2>&1 || { tail -n 5 gpurun_out/$tag.log; exit 1; }
+    timeout -s KILL 150 rocprofv3 --pmc $c -d gpurun_out/$tag -- python3 bench.py --steps 3 --warmup 1 --workload $wl --no-others --no-scaling --no-allpairs --no-cpu-baseline > gpurun_out/$tag.log 2>&1 || { tail -n 5 gpurun_out/$tag.log; exit 1; }
     db=$(find gpurun_out/$tag -name '*.db' | head -n 1)
     python3 tools/prof_summary.py "$db" > gpurun_out/$tag.txt 2>&1 || exit 1
     [ -n "$KEEP_RAW" ] || rm -rf gpurun_out/$tag gpurun_out/$tag.log
