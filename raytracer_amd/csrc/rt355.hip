@@ -216,8 +216,9 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *tile_count; // [tile_stride] active rays per tile, then exclusive offsets; entry [tiles] = total
     uint32_t *active_rid; // [list_stride] rids of the slot's active rays, tile-major or direction-sorted
     uint32_t *bin_hist;   // [HIST_STRIDE] packet search: rays per (direction bin, counter shard), then offsets
-    uint32_t *bin_id;     // [n] packet search: direction bin of each ray, 0xffffffff = inactive
+    uint32_t *bin_id;     // [n] packet search: counter (direction bin and shard) of each ray that is cast
     uint32_t *bin_rank;   // [n] packet search: rank of the ray among those of its counter
+    uint8_t *face;        // [n] packet search: bit g = the hit casts a shadow ray to light g of the group whose rays are being sorted
     uint32_t tile_stride, list_stride;
     // reflection on searched scenes (allocated when such a frame is rendered), all [..][n]
     uint32_t *lvl_clr;    // [4] colour Shader::shading gave the ray of each level
@@ -729,19 +730,17 @@ __device__ __forceinline__ uint32_t wave_bin_count(uint32_t *__restrict__ hist, 
     if (active && lane == leader_lane) base = atomicAdd(&hist[bin], count);
     return base; // valid in the group's first lane; the lane's rank in its cell is that value + rank
 }
-// position of every active ray in the direction-sorted list: start of its counter's run + rank in it
-__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ bin_id_all,
+// position of every ray that is cast in the direction-sorted list: start of its counter's run + rank in it
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *__restrict__ face, const uint32_t *__restrict__ bin_id_all,
                                                      const uint32_t *__restrict__ bin_rank_all,
                                                      const uint32_t *__restrict__ offsets_all,
                                                      uint32_t *__restrict__ active_rid_all, uint32_t n_rays,
                                                      uint32_t list_stride, Slots sl) {
     const size_t g = (size_t)sl.slot[blockIdx.y];
-    const uint32_t *__restrict__ bin_id = bin_id_all + g * n_rays, *__restrict__ bin_rank = bin_rank_all + g * n_rays;
-    const uint32_t *__restrict__ offsets = offsets_all + g * HIST_STRIDE;
-    uint32_t *__restrict__ active_rid = active_rid_all + g * list_stride;
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // the ray count is a multiple of the block size
-    uint32_t bin = bin_id[rid];
-    if (bin != 0xffffffffu) active_rid[offsets[hist_index(bin, rid)] + bin_rank[rid]] = rid;
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // the ray count is a multiple of the block size
+    if (!((face[rid] >> g) & 1u)) return;
+    const size_t at = g * n_rays + rid;
+    active_rid_all[g * list_stride + offsets_all[g * HIST_STRIDE + bin_id_all[at]] + bin_rank_all[at]] = rid;
 }
 
 // Offsets of the direction bins, with every run of 16 consecutive bins (a 4x4 patch of cells on
@@ -1987,8 +1986,12 @@ __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const
                                                      uint32_t rid, bool in_range, bool hit, d3 ph, d3 nh, bool soft) {
     if (soft) return 0u; // (the shadow rays of CalcSoftShadow share neither origin nor direction: none is searched, and the shading kernel counts them)
     uint32_t n_shadow = 0;
-    // the counter value every lane's cell had before this wave arrived, still in flight (one returning
-    // atomic per light): all lights' atomics are issued before any result is used
+    // Rays of binned bundles are counted into the direction bins: the counter value every lane's cell had before this
+    // wave arrived is still in flight (one returning atomic per wave, cell and light) while the other lights are
+    // dealt with.  Which lights the hit faces goes into one byte per ray; counter and rank are written for the rays
+    // that are cast only (for eight lights that is half the ray slots).
+    uint32_t facing = 0;
+    bool any_binned = false;
     uint32_t pending[LIGHT_GROUP], rank_in_wave[LIGHT_GROUP], leader[LIGHT_GROUP];
 #pragma unroll
     for (int g = 0; g < LIGHT_GROUP; g++) {
@@ -1998,8 +2001,27 @@ __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const
         const size_t at = (size_t)g * w.n + rid;
         uint32_t bin = 0xffffffffu;
         if (hit) {
-            d3 nhl = light_nhl(sh.lights[gr.k0 + g], ph);
-            bool needs = !(dot(nh, vmul(nhl, -1)) <= 0); // shader.h:396
+            // shader.h:396 casts the ray unless nh . (-nhl) <= 0, nhl = Normalize(ph - position).  The sign of that
+            // sum is the sign of -(nh . (ph - position)) whenever the latter is not within rounding of zero (the
+            // normalised components carry < 5 units of roundoff each, the sum below < 3; 2^-47 of the terms'
+            // magnitudes is 64 units), and the fp32 search record only needs the direction to ~1e-9: so the square
+            // root and the three divisions of the normalisation are made only for a hit that is tangent to the
+            // light within rounding (or degenerate), which then takes the reference's own operations.
+            const DLight &L = sh.lights[gr.k0 + g];
+            d3 nhl;
+            bool needs;
+            const d3 v = vsub(ph, ld3(L.position));
+            const double px = nh.x * v.x, py = nh.y * v.y, pz = nh.z * v.z, len2 = v.x * v.x + v.y * v.y + v.z * v.z;
+            const double sum = px + py + pz, mag = fabs(px) + fabs(py) + fabs(pz);
+            if (L.type != 0 && fabs(sum) > mag * 0x1p-47 && len2 > 1e-200 && len2 < 1e200) {
+                needs = sum < 0;
+                double y = __builtin_amdgcn_rsq(len2);           // ~2^-26; one Newton step: ~2^-51
+                y = fma(y * 0.5, fma(-len2 * y, y, 1.0), y);
+                nhl = vmul(v, y);
+            } else {
+                nhl = light_nhl(L, ph);
+                needs = !(dot(nh, vmul(nhl, -1)) <= 0);
+            }
             n_shadow += needs ? 1u : 0u;
             if (bd.kind) {
                 float4 q = needs ? bundle_ray(bd, ph, nhl) : nan4();
@@ -2010,17 +2032,18 @@ __device__ __forceinline__ uint32_t emit_shadow_rays(const ShaderView &sh, const
             w.ray32[at] = nan4();
         }
         if (bd.binned) {
-            pending[g] = wave_bin_count(w.bin_hist + (size_t)g * HIST_STRIDE,
-                                        bin != 0xffffffffu ? hist_index(bin, rid) : bin, bin != 0xffffffffu,
-                                        rank_in_wave[g], leader[g]);
-            if (in_range) w.bin_id[at] = bin;
+            const uint32_t counter = bin != 0xffffffffu ? hist_index(bin, rid) : bin;
+            pending[g] = wave_bin_count(w.bin_hist + (size_t)g * HIST_STRIDE, counter, bin != 0xffffffffu, rank_in_wave[g], leader[g]);
+            any_binned = true;
+            if (bin != 0xffffffffu) { facing |= 1u << g; w.bin_id[at] = counter; }
         }
     }
+    if (any_binned && in_range) w.face[rid] = (uint8_t)facing;
 #pragma unroll
     for (int g = 0; g < LIGHT_GROUP; g++) {
         if (g >= gr.count || !gr.b[g].binned) continue; // uniform
         const uint32_t base = (uint32_t)__shfl((int)pending[g], (int)leader[g], 64);
-        if (in_range) w.bin_rank[(size_t)g * w.n + rid] = base + rank_in_wave[g];
+        if ((facing >> g) & 1u) w.bin_rank[(size_t)g * w.n + rid] = base + rank_in_wave[g];
     }
     return n_shadow;
 }
@@ -3866,7 +3889,7 @@ static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
                   w.heavy.list, w.heavy.count,
-                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d,
+                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.face, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d,
                   w.g_live};
     for (void *p : ps) if (p) (void)hipFree(p);
     sc->g_live_rows = 0;
@@ -3992,6 +4015,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.bin_hist, g * HIST_STRIDE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_id, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_rank, g * n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.face, n * sizeof(uint8_t)));
     sc->work_rays = cap_rays;
     sc->work_slots = cap_slots;
     w.n = n_rays;
@@ -4353,7 +4377,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         const uint32_t *total; uint32_t total_stride;
         if (opts->mode == RT355_MODE_PACKET) { // the producer of the rays counted them into direction bins: order them
             hipLaunchKernelGGL(k_scan_bins, dim3((unsigned)searched.count), dim3(1024), 0, st, w.bin_hist, w.active_rid, w.list_stride, searched);
-            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks, (unsigned)searched.count), dim3(256), 0, st, w.bin_id, w.bin_rank, w.bin_hist, w.active_rid, f.n_rays, w.list_stride, searched);
+            hipLaunchKernelGGL(k_bin_scatter, dim3(per_ray_blocks, (unsigned)searched.count), dim3(256), 0, st, w.face, w.bin_id, w.bin_rank, w.bin_hist, w.active_rid, f.n_rays, w.list_stride, searched);
             total = w.bin_hist + HIST_TOTAL; total_stride = HIST_STRIDE;
         } else { // shadow bundles are sparse: compact their active rays first
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles, (unsigned)searched.count), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, searched);
