@@ -218,6 +218,8 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     uint32_t *bin_hist;   // [HIST_STRIDE] packet search: rays per (direction bin, counter shard), then offsets
     uint32_t *bin_id;     // [n] packet search: counter (direction bin and shard) of each ray that is cast
     uint32_t *bin_rank;   // [n] packet search: rank of the ray among those of its counter
+    uint32_t *far_list;   // [n] the hits of the level being shaded that lie far outside the scene (see FAR_SCALE), and
+    uint32_t *far_n;      // [1] their number
     uint8_t *face;        // [n] packet search: bit g = the hit casts a shadow ray to light g of the group whose rays are being sorted
     uint32_t tile_stride, list_stride;
     // reflection on searched scenes (allocated when such a frame is rendered), all [..][n]
@@ -226,6 +228,12 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     double *ktotal;       // reflection_ktotal after the deepest level so far
     uint32_t *deepest;    // deepest level the chain of this sub-sample reached
     double *ray_d;        // [6] the ray of the level being traced: pe.xyz, npe.xyz
+    // The rays of a level after the first are numbered densely, in the order of the level's compacted list: dense
+    // index d < lvl_live[level] stands for ray dense_rid[d] of the frame, and every per-ray array of the level (hit
+    // record, fp32 records, candidates, bins) is indexed by d, so that the level's kernels run over its live chains
+    // only; the arrays that outlive a level (ray_d, ktotal, deepest, lvl_clr, lvl_ks) stay indexed by the frame's rid.
+    uint32_t *lvl_live;   // [4] live chains of each level
+    uint32_t *dense_rid;  // [n] the frame's rid of dense index d of the level being traced
     // the gather shaders on searched scenes (allocated when such a frame is rendered), see k_gather_init
     unsigned long long *g_live; // [ceil(dirs / 64)][n] bit i: the hit sends a ray in direction i
 };
@@ -1619,20 +1627,24 @@ __global__ __launch_bounds__(256) void k_search_general(GeneralTable t, SceneVie
                                                         const uint32_t *__restrict__ list,
                                                         const uint32_t *__restrict__ n_listed, uint32_t n_rays,
                                                         uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_cnt,
-                                                        Spill sp, unsigned long long *__restrict__ counters) {
-    // the rays of this level, compacted in tile order (k_scatter_active): 64 neighbours on screen per wave
+                                                        Spill sp, unsigned long long *__restrict__ counters,
+                                                        uint32_t *__restrict__ live_out) {
+    // the rays of this level, compacted in tile order (k_scatter_active): 64 neighbours on screen per wave; their
+    // candidates are kept under the position in that list, the level's dense numbering (see Work::dense_rid)
     const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const size_t n = n_rays;
     const bool active = at < *n_listed;
-    const uint32_t rid = active ? list[at] : 0u;
+    if (at == 0) *live_out = *n_listed; // (the list's own count is overwritten when the lights' rays are compacted)
+    const uint32_t src = active ? list[at] : 0u; // the frame's rid: where the ray lies
+    const uint32_t rid = at;
     float ox = 0, oy = 0, oz = 0, ux = 0, uy = 0, uz = 0;
     bool odd = false; // a ray the beam cannot hold (no direction, not finite): left to the fp64 walk
     Ray e;
     e.pe = D3(0, 0, 0); e.npe = D3(0, 0, 0);
     if (active) {
-        e.pe = D3(ray_d[0 * n + rid], ray_d[1 * n + rid], ray_d[2 * n + rid]);
-        e.npe = D3(ray_d[3 * n + rid], ray_d[4 * n + rid], ray_d[5 * n + rid]);
+        e.pe = D3(ray_d[0 * n + src], ray_d[1 * n + src], ray_d[2 * n + src]);
+        e.npe = D3(ray_d[3 * n + src], ray_d[4 * n + src], ray_d[5 * n + src]);
         ox = (float)e.pe.x; oy = (float)e.pe.y; oz = (float)e.pe.z;
         ux = (float)e.npe.x; uy = (float)e.npe.y; uz = (float)e.npe.z;
         const float ul = ux * ux + uy * uy + uz * uz, ol = fabsf(ox) + fabsf(oy) + fabsf(oz);
@@ -2955,25 +2967,28 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
                                                          unsigned char *__restrict__ pixmap) {
     Frame f = f_in;
     if (!LEVELS) f.level = -1;
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // (a level after the first: the dense index, see Work::dense_rid)
+    uint32_t out_rid = rid;                               // ... and the frame's rid, under which the level's colour is kept
     uint32_t n_eval = 0, n_over = 0, n_hit = 0;
     bool got_hit = false;
     d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
     do {
     if (rid >= f.n_rays) break;
-    int x, y;
-    rid_to_xy(rid, f.tiles_x, &x, &y);
-    if (!(x < f.grid_w && y < f.grid_h)) {
-        w.rec_obj[rid] = -2;
-        break;
-    }
+    int x = 0, y = 0;
     Ray e;
-    if (LEVELS && f.level > 0) { // the mirror rays of level f.level (k_reflect_rays left them in ray_d); -2 = this chain has ended
-        if (w.deepest[rid] != (uint32_t)f.level) { w.rec_obj[rid] = -2; break; }
+    if (LEVELS && f.level > 0) { // the mirror rays of level f.level (k_reflect_rays left them in ray_d), in the order of their compacted list
+        if (rid >= w.lvl_live[f.level]) break;
+        out_rid = w.active_rid[rid];
+        w.dense_rid[rid] = out_rid;
         const size_t n = f.n_rays;
-        e.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
-        e.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
+        e.pe = D3(w.ray_d[0 * n + out_rid], w.ray_d[1 * n + out_rid], w.ray_d[2 * n + out_rid]);
+        e.npe = D3(w.ray_d[3 * n + out_rid], w.ray_d[4 * n + out_rid], w.ray_d[5 * n + out_rid]);
     } else {
+        rid_to_xy(rid, f.tiles_x, &x, &y);
+        if (!(x < f.grid_w && y < f.grid_h)) {
+            w.rec_obj[rid] = -2;
+            break;
+        }
         e = grid_ray(cam, f, x, y);
     }
     Closest c;
@@ -2983,18 +2998,18 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
         closest_hit<false, ENV>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
     if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
         w.rec_obj[rid] = -1;
-        if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, 0u);
+        if (sh.n_lights == 0) store_pixel(pixmap, f, w, out_rid, x, y, 0u);
         break;
     }
     n_hit = f.level > 0 ? 0 : 1; // rt355_stats.primary_hits counts camera rays
     const bool environment = ENV && s.objects[s.prim_obj[c.prim_best]].type == RT_OBJ_ENVIRONMENT;
     if (sh.n_lights == 0 && f.level < 0 && !environment) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
         w.rec_obj[rid] = s.prim_obj[c.prim_best];
-        store_pixel(pixmap, f, w, rid, x, y, 0u);
+        store_pixel(pixmap, f, w, out_rid, x, y, 0u);
         break;
     }
     const HitRec h = primary_record<ENV>(s, sh, e, c);
-    if (sh.n_lights == 0) store_pixel(pixmap, f, w, rid, x, y, h.emissive ? h.cm0 : 0u); // (levels: the mirror ray still needs ph and nh)
+    if (sh.n_lights == 0) store_pixel(pixmap, f, w, out_rid, x, y, h.emissive ? h.cm0 : 0u); // (levels: the mirror ray still needs ph and nh)
     ph = h.ph; nh = h.nh;
     got_hit = !h.emissive; // an Environment is not lit: no shadow rays (shader.h:70-72)
     const size_t n = f.n_rays;
@@ -3004,7 +3019,10 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
     w.rec_d[6 * n + rid] = h.reh.x; w.rec_d[7 * n + rid] = h.reh.y; w.rec_d[8 * n + rid] = h.reh.z;
     if (!h.no_border) w.rec_d[9 * n + rid] = h.border_w;
     const bool far = !(fabs(ph.x) + fabs(ph.y) + fabs(ph.z) < s.far_origin); // see FAR_SCALE
-    if (far && !h.emissive && sh.n_lights) atomicAdd(&w.counters[15], 1ull);     // (rare: one atomic per such hit)
+    if (far && !h.emissive && sh.n_lights) { // (rare: two atomics per such hit)
+        atomicAdd(&w.counters[15], 1ull);
+        w.far_list[atomicAdd(w.far_n, 1u)] = rid;
+    }
     w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u) | (h.emissive ? (1u << 25) : 0u) | (far ? (1u << 26) : 0u);
     w.rec_cm1[rid] = h.cm1;
     } while (0);
@@ -3020,24 +3038,35 @@ __global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView
 // main.cpp:94), reflection_ktotal *= ks, reflection_times = level + 1, and while both thresholds hold
 // (main.cpp:27-28,103) the mirror ray View(ph, npe - nh * 2 * (nh . npe)), which becomes the ray of level + 1.
 __global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, Frame f, Work w, int level) {
-    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    // level 0: one thread per ray of the frame, every ray's slot-0 record written (NaN where no mirror ray is cast).
+    // A later level: one thread per live chain of that level (dense index, see Work::dense_rid); the records were
+    // cleared to NaN before the launch and only the chains that go on write theirs.
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rid = idx; // the frame's rid
     uint32_t n_secondary = 0;
     float4 rec = nan4(); // slot 0's fp32 record: the direction of a mirror ray, NaN where there is none
+    bool mine = false;   // this thread stands for a ray of the frame
     do {
-    if (rid >= f.n_rays) break;
-    int x, y;
-    rid_to_xy(rid, f.tiles_x, &x, &y);
+    if (idx >= f.n_rays) break;
     const size_t n = f.n_rays;
-    if (!(x < f.grid_w && y < f.grid_h)) { if (level == 0) w.deepest[rid] = 0xffffffffu; break; }
-    if (level == 0) { w.deepest[rid] = 0u; w.ktotal[rid] = 1.0; }
-    else if (w.deepest[rid] != (uint32_t)level) break;
+    int x = 0, y = 0;
+    if (level == 0) {
+        mine = true;
+        rid_to_xy(rid, f.tiles_x, &x, &y);
+        if (!(x < f.grid_w && y < f.grid_h)) { w.deepest[rid] = 0xffffffffu; break; }
+        w.deepest[rid] = 0u; w.ktotal[rid] = 1.0;
+    } else {
+        if (idx >= w.lvl_live[level]) break;
+        mine = true;
+        rid = w.dense_rid[idx];
+    }
     Ray e;
     if (level == 0) e = grid_ray(cam, f, x, y);
     else {
         e.pe = D3(w.ray_d[0 * n + rid], w.ray_d[1 * n + rid], w.ray_d[2 * n + rid]);
         e.npe = D3(w.ray_d[3 * n + rid], w.ray_d[4 * n + rid], w.ray_d[5 * n + rid]);
     }
-    const int obj = w.rec_obj[rid];
+    const int obj = w.rec_obj[idx];
     int miss_obj = 0; // what a ray that misses goes on with: object_index as CalcSubPixel received it
     if (f.soft && level == 0) { const SoftArgs a = soft_args(f, x, y); if (a.obj0 < s.n_objects) miss_obj = a.obj0; }
     const double ks = s.n_objects > 0 ? s.objects[obj >= 0 ? obj : miss_obj].ks : 0.0; // main.cpp:94
@@ -3047,8 +3076,8 @@ __global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, 
     if (!((level + 1 <= 3) && (ktotal >= 0.05) && s.n_objects > 0)) break;       // :98-103
     d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
     if (obj >= 0) {
-        ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
-        nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+        ph = D3(w.rec_d[0 * n + idx], w.rec_d[1 * n + idx], w.rec_d[2 * n + idx]);
+        nh = D3(w.rec_d[3 * n + idx], w.rec_d[4 * n + idx], w.rec_d[5 * n + idx]);
     }
     const Ray r = mkview(ph, vsub(e.npe, vmul(vmul(nh, 2), dot(nh, e.npe))));   // :104-108
     w.ray_d[0 * n + rid] = r.pe.x; w.ray_d[1 * n + rid] = r.pe.y; w.ray_d[2 * n + rid] = r.pe.z;
@@ -3059,7 +3088,7 @@ __global__ __launch_bounds__(256) void k_reflect_rays(SceneView s, DCamera cam, 
     if (!(rec.x == rec.x)) rec.x = 0.f;
     n_secondary = 1;
     } while (0);
-    if (rid < f.n_rays) w.ray32[rid] = rec;
+    if (level == 0 ? idx < f.n_rays : (mine && n_secondary)) w.ray32[rid] = rec;
     wave_count(w.counters, 6, n_secondary);
 }
 
@@ -3086,33 +3115,27 @@ __global__ __launch_bounds__(256) void k_fold_levels(Frame f, Work w, unsigned c
 // becomes the ray's whole candidate list for that light, which the shading kernel then walks as any other.
 // Frames without such hits leave at the first line.
 __global__ __launch_bounds__(256) void k_shade_far(SceneView s, ShaderView sh, Frame f, Work w, Group cur) {
-    if (w.counters[15] == 0) return;
-    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool far = rid < f.n_rays && w.rec_obj[rid] >= 0 && ((w.rec_cm0[rid] >> 25) & 3u) == 2u; // far, not emissive
-    d3 fp = D3(0, 0, 0), fn = D3(0, 0, 0);
-    if (far) {
+    const uint32_t n_far = *w.far_n;
+    if (n_far == 0) return;
+    // one (hit, light) pair per wave and turn, whichever wave comes next: far hits lie together on screen (a floor's
+    // horizon), and taken by the waves that own them a few waves would run 64 x lights walks each
+    const uint32_t n_waves = gridDim.x * (blockDim.x / 64u), n_tasks = n_far * (uint32_t)cur.count;
+    for (uint32_t task = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; task < n_tasks; task += n_waves) { // uniform in a wave
+        const uint32_t rid = w.far_list[task / (uint32_t)cur.count];
+        const int g = (int)(task % (uint32_t)cur.count);
         const size_t n = f.n_rays;
-        fp = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
-        fn = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
-    }
-    unsigned long long todo = __ballot(far);
-    while (todo) { // uniform
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const d3 p = D3(__shfl(fp.x, src, 64), __shfl(fp.y, src, 64), __shfl(fp.z, src, 64));
-        const d3 nrm = D3(__shfl(fn.x, src, 64), __shfl(fn.y, src, 64), __shfl(fn.z, src, 64));
-        for (int g = 0; g < cur.count; g++) {
-            const DLight &L = sh.lights[cur.k0 + g];
-            const d3 nhl = light_nhl(L, p);
-            if (dot(nrm, vmul(nhl, -1)) <= 0) continue;  // no shadow ray (shader.h:396)
-            Ray sr; // as shade_light builds it
-            if (L.type == 0) { sr.pe = p; sr.npe = ld3(L.shadow_dir); }
-            else sr = mkview(p, vmul(nhl, -1));
-            const int prim = nearest_occluder_wave(s, sr);
-            if ((int)(threadIdx.x & 63) == src) { // the list the shading kernel will walk: that primitive, nothing, or everything
-                w.cand_cnt[(size_t)g * f.n_rays + rid] = prim >= 0 ? 1u : (prim == -1 ? 0u : CAND_UNSEARCHED);
-                if (prim >= 0) w.cand[(size_t)g * CAND_CAP * f.n_rays + rid] = cand_id(s, prim);
-            }
+        const d3 p = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
+        const d3 nrm = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+        const DLight &L = sh.lights[cur.k0 + g];
+        const d3 nhl = light_nhl(L, p);
+        if (dot(nrm, vmul(nhl, -1)) <= 0) continue;  // no shadow ray (shader.h:396)
+        Ray sr; // as shade_light builds it
+        if (L.type == 0) { sr.pe = p; sr.npe = ld3(L.shadow_dir); }
+        else sr = mkview(p, vmul(nhl, -1));
+        const int prim = nearest_occluder_wave(s, sr);
+        if ((threadIdx.x & 63u) == 0) { // the list the shading kernel will walk: that primitive, nothing, or everything
+            w.cand_cnt[(size_t)g * f.n_rays + rid] = prim >= 0 ? 1u : (prim == -1 ? 0u : CAND_UNSEARCHED);
+            if (prim >= 0) w.cand[(size_t)g * CAND_CAP * f.n_rays + rid] = cand_id(s, prim);
         }
     }
 }
@@ -3138,12 +3161,17 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
     do {
     if (rid >= f.n_rays) break;
+    uint32_t out_rid = rid; // a level after the first is numbered densely (see Work::dense_rid): its colour goes to the frame's rid
+    if (f.level > 0) {
+        if (rid >= w.lvl_live[f.level]) break;
+        out_rid = w.dense_rid[rid];
+    }
     int obj = w.rec_obj[rid];
     if (obj == -2) break;
     int x, y;
-    rid_to_xy(rid, f.tiles_x, &x, &y);
+    rid_to_xy(rid, f.tiles_x, &x, &y); // (level <= 0: the grid point, for the pixel and the soft-shadow strata)
     if (obj < 0) {
-        if (last) store_pixel(pixmap, f, w, rid, x, y, 0u);
+        if (last) store_pixel(pixmap, f, w, out_rid, x, y, 0u);
         break;
     }
     const size_t n = f.n_rays;
@@ -3156,7 +3184,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
     h.cm0 = cm0w & 0xffffffu; h.cm1 = w.rec_cm1[rid];
     h.no_border = (cm0w >> 24) & 1u;
     if ((cm0w >> 25) & 1u) { // an Environment: its colour as it is (shader.h:70-72)
-        if (last) store_pixel(pixmap, f, w, rid, x, y, h.cm0);
+        if (last) store_pixel(pixmap, f, w, out_rid, x, y, h.cm0);
         break;
     }
     h.border_w = h.no_border ? 0.0 : w.rec_d[9 * n + rid];
@@ -3199,7 +3227,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
         }, SOFT ? n_soft : unused, soft.m, soft.n);
     }
     if (last) {
-        store_pixel(pixmap, f, w, rid, x, y, sum);
+        store_pixel(pixmap, f, w, out_rid, x, y, sum);
         break;
     }
     w.rec_sum[rid] = sum;
@@ -3889,7 +3917,7 @@ static void free_work(rt355_scene *sc) {
     Work &w = sc->work;
     void *ps[] = {w.rec_d, w.rec_obj, w.rec_cm0, w.rec_cm1, w.rec_sum, w.ray32, w.cand_cnt, w.cand, w.spill.pool, w.spill.count,
                   w.heavy.list, w.heavy.count,
-                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.face, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d,
+                  w.tile_count, w.active_rid, w.bin_hist, w.bin_id, w.bin_rank, w.face, w.far_list, w.far_n, w.lvl_clr, w.lvl_ks, w.ktotal, w.deepest, w.ray_d, w.lvl_live, w.dense_rid,
                   w.g_live};
     for (void *p : ps) if (p) (void)hipFree(p);
     sc->g_live_rows = 0;
@@ -4016,6 +4044,8 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     HIP_TRY(hipMalloc((void **)&w.bin_id, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.bin_rank, g * n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&w.face, n * sizeof(uint8_t)));
+    HIP_TRY(hipMalloc((void **)&w.far_list, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&w.far_n, sizeof(uint32_t)));
     sc->work_rays = cap_rays;
     sc->work_slots = cap_slots;
     w.n = n_rays;
@@ -4059,12 +4089,13 @@ static int rows_of(const rt355_opts *opts, Rows *out) {
 // The level / gather arrays of the workspace: all five or none (a frame that needs them launches kernels on all).
 static int ensure_levels(rt355_scene *sc) {
     Work &wk = sc->work;
-    if (wk.lvl_clr && wk.lvl_ks && wk.ktotal && wk.deepest && wk.ray_d) return RT355_OK;
+    if (wk.lvl_clr && wk.lvl_ks && wk.ktotal && wk.deepest && wk.ray_d && wk.lvl_live && wk.dense_rid) return RT355_OK;
     const size_t cap = sc->work_rays;
     auto drop = [&]() {
-        void *ps[] = {wk.lvl_clr, wk.lvl_ks, wk.ktotal, wk.deepest, wk.ray_d};
+        void *ps[] = {wk.lvl_clr, wk.lvl_ks, wk.ktotal, wk.deepest, wk.ray_d, wk.lvl_live, wk.dense_rid};
         for (void *q : ps) if (q) (void)hipFree(q);
         wk.lvl_clr = nullptr; wk.lvl_ks = nullptr; wk.ktotal = nullptr; wk.deepest = nullptr; wk.ray_d = nullptr;
+        wk.lvl_live = nullptr; wk.dense_rid = nullptr;
     };
     drop();
     hipError_t e;
@@ -4072,7 +4103,9 @@ static int ensure_levels(rt355_scene *sc) {
         (e = hipMalloc((void **)&wk.lvl_ks, 4 * cap * sizeof(double))) == hipSuccess &&
         (e = hipMalloc((void **)&wk.ktotal, cap * sizeof(double))) == hipSuccess &&
         (e = hipMalloc((void **)&wk.deepest, cap * sizeof(uint32_t))) == hipSuccess &&
-        (e = hipMalloc((void **)&wk.ray_d, 6 * cap * sizeof(double))) == hipSuccess)
+        (e = hipMalloc((void **)&wk.ray_d, 6 * cap * sizeof(double))) == hipSuccess &&
+        (e = hipMalloc((void **)&wk.lvl_live, 4 * sizeof(uint32_t))) == hipSuccess &&
+        (e = hipMalloc((void **)&wk.dense_rid, cap * sizeof(uint32_t))) == hipSuccess)
         return RT355_OK;
     drop();
     return fail(RT355_ERR_DEVICE, std::string("level arrays: ") + hipGetErrorString(e));
@@ -4465,6 +4498,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     auto tail_part_of_turn = [&](int turn) { return tail_top_first ? tail_parts - 1 - turn : turn; };
     auto tail_finish = [&](int p, bool last_turn) -> int {
         const int ya = tail_tile_row(p) * TILE_H, yb = std::min(f.rows, tail_tile_row(p + 1) * TILE_H);
+        if (ya >= yb) return RT355_OK; // (a frame of fewer tile rows than parts)
         Frame fp = f;
         fp.rid_base = tail_first_rid(p);
         fp.avg_row0 = ya;
@@ -4505,7 +4539,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, one);
             hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
             hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
-                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters);
+                               w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters, w.lvl_live + L);
             HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
             sc->launch_choice.push_back({-1, 0});
             launches++;
@@ -4513,6 +4547,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         Group cur = group_of(0);
         int rc1 = clear_bins(cur);
         if (rc1) return rc1;
+        HIP_TRY(hipMemsetAsync(w.far_n, 0, sizeof(uint32_t), st)); // (the far hits of this level: listed by the kernel below)
         HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
         {
             const int brute_l = (L == 0 && !bundles[0].kind) ? 1 : 0;
@@ -4529,15 +4564,18 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             Group next = group_of(j + 1);
             if ((rc1 = clear_bins(next))) return rc1;
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
-            hipLaunchKernelGGL(k_shade_far, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, fl, w, cur);
+            hipLaunchKernelGGL(k_shade_far, dim3(std::min(per_ray_blocks, 2048u)), dim3(256), 0, st, sc->view, sh, fl, w, cur);
             // the frame's last shading launch goes part by part when the caller reads the parts back meanwhile (the
             // time recorded for it then includes the parts' folds and k_average launches)
             const bool in_parts = tail_parts > 1 && L == extra_levels && j == n_groups - 1;
-            for (int turn = 0; turn < (in_parts ? tail_parts : 1); turn++) {
+            // (the rays of a level after the first are numbered densely, not by where they are on screen: such a
+            // level is shaded in one launch, and only the fold and the pixels come part by part)
+            const bool shade_in_parts = in_parts && L == 0;
+            for (int turn = 0; turn < (shade_in_parts ? tail_parts : 1); turn++) {
                 const int p = tail_part_of_turn(turn);
                 Frame fp = fl;
                 unsigned blocks = per_ray_blocks;
-                if (in_parts) {
+                if (shade_in_parts) {
                     fp.rid_base = tail_first_rid(p);
                     blocks = (tail_first_rid(p + 1) - fp.rid_base) / 256u;
                     if (blocks == 0) continue; // (a frame of fewer tile rows than parts)
@@ -4548,8 +4586,10 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
                     hipLaunchKernelGGL(k_shade_group<true>, dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
                 else
                     hipLaunchKernelGGL(k_shade_group<false>, dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
-                if (in_parts && (rc1 = tail_finish(p, turn == tail_parts - 1))) return rc1;
+                if (shade_in_parts && (rc1 = tail_finish(p, turn == tail_parts - 1))) return rc1;
             }
+            for (int turn = 0; in_parts && !shade_in_parts && turn < tail_parts; turn++)
+                if ((rc1 = tail_finish(tail_part_of_turn(turn), turn == tail_parts - 1))) return rc1;
             if (in_parts) tail_done = true;
             HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
             resolves++;
@@ -4599,6 +4639,8 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     } else if (can_search) {
         if ((rc = run_level(0))) return rc;
         for (int L = 0; L < extra_levels; L++) {
+            // (after the first level only the chains that go on write their slot-0 record: the others' must read "no ray")
+            if (L > 0) HIP_TRY(hipMemsetAsync(w.ray32, 0xff, (size_t)f.n_rays * sizeof(float4), st));
             hipLaunchKernelGGL(k_reflect_rays, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, dc, f, w, L);
             if ((rc = run_level(L + 1))) return rc;
         }
