@@ -356,7 +356,7 @@ def measure(name, args, ctx, light=False):
                 rc = rt355_render(*part_args)
                 if rc:
                     _check(rc, "rt355_render")
-                host_barrier(dist)
+                shared.barrier()  # (arrival counters in the shared mapping itself: microseconds, no collective)
                 st = st_part.as_dict()
                 return count_rays(st), st
             # this rank's rows into its framebuffer in HBM, the final frame gathered on rank 0 (RCCL), read back there

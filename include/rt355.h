@@ -395,6 +395,8 @@ double rt355_strata(uint32_t seed, int32_t x, int32_t y, int32_t which);
  *   "heavy_min_prims" the packet search runs as two launches from this many primitives (default 300000; 0 = always),
  *   "heavy_after"     a wave handing the rest of its walk over after this many primitives (default 256)
  *   "heavy_workers"   to this many waves (default 16)
+ *   "heavy_small_rays" a call of at most this many rays (default 6291456: a share of a frame) searches a scene of 32768
+ *                     primitives or more in two launches too, handing over after 64 (0 = never)
  *   "gather_general"  1 = the gather shaders' general kernel also for scenes of at most four planes and spheres
  *   "walk_blocks"     workgroups of the searched gather's walk (default 8192)
  *   "gather"          multi-device scenes only: 0 = every GPU writes its rows into the host pixmap (default), 1 = rows

@@ -109,6 +109,14 @@ __device__ __forceinline__ void append_id_shared(uint32_t id, uint32_t rid, uint
 #define HEAVY_MIN_PRIMS 300000 // scenes below this are searched in one launch (the second costs 0.02 ms and gains nothing there)
 #ifndef HEAVY_WORKERS
 #define HEAVY_WORKERS 16u   // waves that share what one such wave left
+// A launch lasts as long as its longest wave, and the fewer waves it has the more that wave weighs: a call that renders
+// a share of a frame (one of several GPUs' tiles) hands over earlier, and does so in smaller scenes too.  Measured on
+// tile shares, ms per frame with / without: 100 000 triangles at 3840x2160, half 0.71 / 0.79, quarter 0.47 / 0.55,
+// eighth 0.38 / 0.47 (the whole frame: no difference); a million triangles at 7680x4320, eighth 1.08 / 1.14 (quarter
+// and half: no gain, so the limit is six million rays); 10 000 spheres: no gain at any size.
+#define HEAVY_SMALL_RAYS (6u << 20)
+#define HEAVY_SMALL_PRIMS 32768
+#define HEAVY_SMALL_AFTER 64u
 #endif
 #ifndef HEAVY_AFTER
 #define HEAVY_AFTER 256u    // primitives met (64 pair tests each) after which a wave hands over
@@ -2666,7 +2674,11 @@ __global__ __launch_bounds__(256) void k_render_gather(SceneView s, ShaderView s
 // every hit its two angles and marks the directions of the set that, turned by them, pass the normal test;
 // k_gather_walk sends those rays through the scene table and adds what they hit to the hit's counts and colour
 // sums; k_gather_finish blends the pixel.  The per-hit state lives in the arrays the levels of mirror rays use:
-// lvl_ks[0..3] = sin and cos of the two angles, lvl_clr[0] = cnt, lvl_clr[1..3] = the colour sums.
+// lvl_ks[0..3] = sin and cos of the two angles, lvl_clr[0] = cnt, lvl_clr[1..3] = the colour sums -- or, for a set
+// of at most GATHER_PACKED_DIRS directions (each sum then fits 16 bits), all four in one 64-bit word per hit, the first
+// 2 n words of lvl_clr read as n such words: cnt << 48 | red << 32 | green << 16 | blue, so that a gather ray adds its
+// hit with ONE atomic instead of four (every device-wide atomic is a transaction with memory of its own).
+#define GATHER_PACKED_DIRS 256
 __device__ __forceinline__ d3 gather_ray(const Gather &ga, int i, double s1, double c1, double s2, double c2) {
     const double gx = ga.dirs[3 * i], gy = ga.dirs[3 * i + 1], gz = ga.dirs[3 * i + 2];
     const double x1 = c1 * gx - s1 * gy, y1 = s1 * gx + c1 * gy;                          // shader.h:115,160
@@ -2694,7 +2706,8 @@ __global__ __launch_bounds__(256) void k_gather_init(Frame f, Work w, Gather ga)
     sincos_rounded(theta1, &s1, &c1);
     sincos_rounded(theta2, &s2, &c2);
     w.lvl_ks[0 * n + rid] = s1; w.lvl_ks[1 * n + rid] = c1; w.lvl_ks[2 * n + rid] = s2; w.lvl_ks[3 * n + rid] = c2;
-    w.lvl_clr[0 * n + rid] = 0u; w.lvl_clr[1 * n + rid] = 0u; w.lvl_clr[2 * n + rid] = 0u; w.lvl_clr[3 * n + rid] = 0u;
+    if (ga.n <= GATHER_PACKED_DIRS) ((unsigned long long *)w.lvl_clr)[rid] = 0ull; // (shading2 counts in its low half)
+    else { w.lvl_clr[0 * n + rid] = 0u; w.lvl_clr[1 * n + rid] = 0u; w.lvl_clr[2 * n + rid] = 0u; w.lvl_clr[3 * n + rid] = 0u; }
     const d3 nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
     unsigned long long live = 0ull;
     for (int i = 0; i < ga.n; i++) {
@@ -2773,11 +2786,15 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
         if (BLEED) {
             if (bt < 100) {                                                               // shader.h:181-184
                 const uint32_t hc = s.objects[s.prim_obj[bprim]].rgb;
-                atomicAdd(&w.lvl_clr[1 * n + rid], cr(hc)); atomicAdd(&w.lvl_clr[2 * n + rid], cg(hc)); atomicAdd(&w.lvl_clr[3 * n + rid], cb(hc));
-                atomicAdd(&w.lvl_clr[0 * n + rid], 2u);
+                if (ga.n <= GATHER_PACKED_DIRS) { // uniform
+                    atomicAdd((unsigned long long *)w.lvl_clr + rid, (2ull << 48) | ((unsigned long long)cr(hc) << 32) | ((unsigned long long)cg(hc) << 16) | (unsigned long long)cb(hc));
+                } else {
+                    atomicAdd(&w.lvl_clr[1 * n + rid], cr(hc)); atomicAdd(&w.lvl_clr[2 * n + rid], cg(hc)); atomicAdd(&w.lvl_clr[3 * n + rid], cb(hc));
+                    atomicAdd(&w.lvl_clr[0 * n + rid], 2u);
+                }
             }
         } else if (bprim >= 0) {                                                          // :130-133
-            atomicAdd(&w.lvl_clr[0 * n + rid], 2u);
+            atomicAdd(ga.n <= GATHER_PACKED_DIRS ? &w.lvl_clr[2 * (size_t)rid] : &w.lvl_clr[0 * n + rid], 2u);
         }
         has = false;
     };
@@ -2946,12 +2963,21 @@ __global__ __launch_bounds__(256) void k_gather_finish(SceneView s, ShaderView s
     uint32_t clr = 0u; // main.cpp:167,204
     if (obj >= 0) {
         const size_t n = f.n_rays;
-        const uint32_t cnt = w.lvl_clr[0 * n + rid];
+        uint32_t cnt, sr = 0u, sg = 0u, sb = 0u;
+        if (BLEED && ga.n <= GATHER_PACKED_DIRS) { // the four sums in one word (see k_gather_init)
+            const unsigned long long word = ((const unsigned long long *)w.lvl_clr)[rid];
+            cnt = (uint32_t)(word >> 48); sr = (uint32_t)(word >> 32) & 0xffffu; sg = (uint32_t)(word >> 16) & 0xffffu; sb = (uint32_t)word & 0xffffu;
+        } else if (ga.n <= GATHER_PACKED_DIRS) { // shading2: the count alone, in the word's low half
+            cnt = w.lvl_clr[2 * (size_t)rid];
+        } else {
+            cnt = w.lvl_clr[0 * n + rid];
+            if (BLEED) { sr = w.lvl_clr[1 * n + rid]; sg = w.lvl_clr[2 * n + rid]; sb = w.lvl_clr[3 * n + rid]; }
+        }
         const double part = (double)(int)cnt * 1.0 / (double)ga.n;                         // shader.h:137,188
         uint32_t other = sh.ambient;
         if (BLEED) {
             const double m = (double)(int)cnt;                                             // :187
-            other = RGB(q8((double)w.lvl_clr[1 * n + rid] / m), q8((double)w.lvl_clr[2 * n + rid] / m), q8((double)w.lvl_clr[3 * n + rid] / m));
+            other = RGB(q8((double)sr / m), q8((double)sg / m), q8((double)sb / m));
         }
         clr = cadd(cmul(s.objects[obj].rgb, 1 - part), cmul(other, part));
     }
@@ -3222,6 +3248,9 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void k_shade_group(SceneView 
             dbg_n[g] = cur.b[g].kind ? w.cand_cnt[(size_t)g * n + rid] : 0u;
 #endif
             const bool brute = SOFT || cur.b[g].kind == 0;
+#ifdef RT355_TIMING_NO_OCCLUDER /* timing-only build: what the kernel costs without the candidates' tests (frames differ) */
+            if (!brute) return (double)RT_FLT_MAX;
+#endif
             return nearest_occluder<ENV>(s, sr, brute, rid, f.n_rays, w.cand + (size_t)g * CAND_CAP * n,
                                     w.cand_cnt + (size_t)g * n, sp, n_eval, n_over, (brute || !SHADE_PREFETCH) ? nullptr : &pre);
         }, SOFT ? n_soft : unused, soft.m, soft.n);
@@ -3341,6 +3370,8 @@ struct Knobs {
     int64_t heavy_min_prims = HEAVY_MIN_PRIMS; // packet search in two launches from this many primitives (0: always)
     int64_t heavy_after = HEAVY_AFTER;         // ... a wave hands over after this many primitives met
     int64_t heavy_workers = HEAVY_WORKERS;     // ... to this many waves
+    int64_t heavy_small_rays = HEAVY_SMALL_RAYS; // a call of at most this many rays (a share of a frame) searches a scene of
+                                               // HEAVY_SMALL_PRIMS primitives or more in two launches too, handing over after HEAVY_SMALL_AFTER (0: never)
     int64_t packet_rays = 0;                   // rays per lane of the packet search: 1 or 4 (0: timed on the first frames)
     int64_t gather_general = 0;                // 1: the gather shaders' general kernel also for scenes of a few planes and spheres
     int64_t walk_blocks = 8192;                // workgroups of the searched gather's walk
@@ -3354,7 +3385,8 @@ struct Knobs {
 struct KnobName { const char *name; int64_t Knobs::*field; int64_t lo, hi; };
 static const KnobName kKnobs[] = {
     {"heavy_min_prims", &Knobs::heavy_min_prims, 0, INT32_MAX}, {"heavy_after", &Knobs::heavy_after, 1, INT32_MAX},
-    {"heavy_workers", &Knobs::heavy_workers, 1, 1024}, {"packet_rays", &Knobs::packet_rays, 0, 4},
+    {"heavy_workers", &Knobs::heavy_workers, 1, 1024}, {"heavy_small_rays", &Knobs::heavy_small_rays, 0, INT32_MAX},
+    {"packet_rays", &Knobs::packet_rays, 0, 4},
     {"gather_general", &Knobs::gather_general, 0, 1}, {"walk_blocks", &Knobs::walk_blocks, 1, 1 << 20},
     {"readback", &Knobs::readback, 0, 2}, {"render_parts", &Knobs::render_parts, 1, 64}, {"tail_parts", &Knobs::tail_parts, 1, 64},
     {"no_tail_parts", &Knobs::no_tail_parts, 0, 1}, {"tail_bottom_first", &Knobs::tail_bottom_first, 0, 1},
@@ -4340,9 +4372,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             const dim3 grid((unsigned)((n_entries + per_block - 1) / per_block), (unsigned)sl.count);
             // the search, then the waves that share what its longest waves handed over (blocks past the list's end leave at once)
             const dim3 grid_heavy(HEAVY_GRID, (unsigned)sl.count);
-            const bool two_launches = sc->view.n_prims >= heavy_min_prims;
+            const bool small_call = f.n_rays <= (uint64_t)sc->knobs.heavy_small_rays && sc->view.n_prims >= HEAVY_SMALL_PRIMS;
+            const bool two_launches = sc->view.n_prims >= heavy_min_prims || small_call;
             Heavy hv = w.heavy;
             hv.after = (uint32_t)sc->knobs.heavy_after; // (tests: hand over early)
+            if (small_call) hv.after = std::min(hv.after, HEAVY_SMALL_AFTER);
             hv.workers = (uint32_t)sc->knobs.heavy_workers;
             hv.workers = std::max<uint32_t>(PACKET_WAVES, hv.workers / PACKET_WAVES * PACKET_WAVES);
             if (two_launches) HIP_TRY(hipMemsetAsync(w.heavy.count, 0, LIGHT_GROUP * sizeof(uint32_t), st));

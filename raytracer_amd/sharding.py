@@ -69,20 +69,23 @@ class SharedPixmap:
         import os
         import numpy as np
         n = width * height * 3
+        flags_at = (n + 4095) // 4096 * 4096  # behind the pixels, on a page of their own: one arrival counter per rank
+        size = flags_at + 4096
         name = [None]
         self.array = None
         self.registered = False
+        self.rank, self.world, self._epoch = rank, world, 0
         try:
             if rank == 0:
                 name[0] = f"/dev/shm/rt355_pixmap_{os.getpid()}_{id(self):x}"
                 with open(name[0], "wb") as f:
-                    f.truncate(n)
+                    f.truncate(size)
             if world > 1:
                 import torch
                 dist.broadcast_object_list(name, src=0, device=torch.device("cpu"))
             fd = os.open(name[0], os.O_RDWR)
             try:
-                self._map = mmap.mmap(fd, n)
+                self._map = mmap.mmap(fd, size)
             finally:
                 os.close(fd)
             if world > 1:
@@ -92,7 +95,8 @@ class SharedPixmap:
             # ends them), the file's name does not outlive this constructor on rank 0
             if rank == 0 and name[0] and os.path.exists(name[0]):
                 os.unlink(name[0])
-        self.array = np.frombuffer(self._map, dtype=np.uint8).reshape(height, width, 3)
+        self.array = np.frombuffer(self._map, dtype=np.uint8, count=n).reshape(height, width, 3)
+        self._arrived = np.frombuffer(self._map, dtype=np.int64, count=world, offset=flags_at)
         # The HIP runtime of this image refuses to page-lock a mapping that a file backs (/dev/shm and memfd alike):
         # `registered` is then False, the pixmap stays pageable, and rt355_render passes a rank's rows through the
         # handle's own page-locked staging memory and a host copy, part by part as they arrive.  The registered
@@ -102,6 +106,22 @@ class SharedPixmap:
             from .api import lib
             self.registered = lib().rt355_host_register(self.array.ctypes.data, n) == 0
 
+    def barrier(self, timeout_s: float = 120.0):
+        """Every rank's rows of the current frame have been written: each rank publishes how many frames it has
+        finished in its own word of the shared page and waits until no rank is behind it.  Plain loads and stores of
+        the one mapping (x86 keeps their order; each word has one writer), a few microseconds after the last rank
+        arrives -- the frame-complete signal of a frame shared between processes, where a collective over sockets
+        would cost a good part of a share's render time."""
+        import time
+        self._epoch += 1
+        self._arrived[self.rank] = self._epoch
+        t0 = time.perf_counter()
+        spins = 0
+        while int(self._arrived.min()) < self._epoch:
+            spins += 1
+            if spins % 4096 == 0 and time.perf_counter() - t0 > timeout_s:
+                raise TimeoutError(f"rank {self.rank}: the other ranks did not finish frame {self._epoch} within {timeout_s} s")
+
     def close(self):
         if self.array is not None:
             if self.registered:
@@ -109,6 +129,7 @@ class SharedPixmap:
                 lib().rt355_host_unregister(self.array.ctypes.data)
                 self.registered = False
             self.array = None
+            self._arrived = None
             try:
                 self._map.close()
             except BufferError:  # (a view of the array is still alive somewhere: the mapping goes with it)

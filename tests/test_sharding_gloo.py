@@ -37,6 +37,9 @@ def _worker(rank, world, port, out_dir):
     # rows, a barrier, and the frame is whole on every rank
     shared = SharedPixmap(w, h, rank, world, dist, register=False)
     O.render(p, cam, sh, B.opts(w, h, row_begin=b, row_end=e), threads=2, out=shared.array)
+    shared.barrier()  # the frame-complete signal: arrival counters in the mapping itself
+    for _ in range(50):  # (and again and again: a rank may be a whole frame ahead of a slower one, never two)
+        shared.barrier()
     dist.barrier()
     if rank == 0:
         np.save(os.path.join(out_dir, "shared.npy"), shared.array.copy())
