@@ -590,6 +590,9 @@ def measure(name, args, ctx, light=False):
                                "algorithmic_bytes_per_frame": float(3 * w * h),
                                "note": "arithmetic is fp64 (half the fp32 rate); per-hit shading is not in the flop count"
                                        + ("; nor are the tests of the mirror and refracted rays" if stats["secondary_rays"] else "")}
+            iss = measured_issue(name, out["roofline"]["kernel"], avg_ms)  # what bounds it: the share of the vector-issue slots it uses
+            if iss:
+                out["roofline"]["valu_issue_frac"] = iss["frac"]
     else:
         rooflines = {"k_resolve_primary": hbm_roofline("k_resolve_primary", primary_bytes(stats, n_rays_padded, nl, True),
                                                        acc["primary_ms"], K)}
