@@ -963,7 +963,11 @@ def main():
         if world > 1 and args.workload == HEADLINE and not args.no_inproc and not args.no_scaling:
             line["inproc"] = inproc_beside(args, world)
         detail = dict(line, headline=head, other_configs=others, scaling_workloads_detail=scaling)
-        emit(line, detail)
+        # (a run of one workload alone -- the profiling passes -- keeps its record apart from the default run's)
+        full = args.workload == HEADLINE and (others or scaling)
+        if not full:
+            line["detail"] = f"bench_detail_{args.workload}.json"
+        emit(line, detail, detail_name=line["detail"])
     if world > 1:
         dist.destroy_process_group()
 
