@@ -1421,7 +1421,10 @@ __device__ __forceinline__ void packet_search_wave(uint32_t block_x, const Table
 #define HEAVY_GRID 4096u
 #endif
 template <int KIND, int PR, int MODE>
-__global__ __launch_bounds__(PACKET_THREADS) void k_search_packet(Tables t_all, const float4 *__restrict__ ray32_all, uint32_t n_rays,
+#ifndef PACKET_MIN_WAVES
+#define PACKET_MIN_WAVES 1 // waves per SIMD asked of the compiler (1: its own choice -- four with 4 rays a lane, seven with 1)
+#endif
+__global__ __launch_bounds__(PACKET_THREADS, PACKET_MIN_WAVES) void k_search_packet(Tables t_all, const float4 *__restrict__ ray32_all, uint32_t n_rays,
                                                                   const uint32_t *__restrict__ active_rid_all,
                                                                   const uint32_t *__restrict__ n_active_all,
                                                                   uint32_t *__restrict__ cand_all, uint32_t *__restrict__ cand_cnt_all,
@@ -5244,11 +5247,23 @@ extern "C" int rt355_scene_create_multi(const rt355_scene_desc *d, const int32_t
     sc->multi = new MultiScene();
     sc->device = devices[0];
     int rc = RT355_OK;
-    for (int i = 0; i < n_devices && rc == RT355_OK; i++) { // the scene replicated: flattened and uploaded once per device
-        if (hipSetDevice(devices[i]) != hipSuccess) { (void)hipGetLastError(); rc = fail(RT355_ERR_DEVICE, "hipSetDevice failed"); break; }
-        rt355_scene *r = nullptr;
-        rc = rt355_scene_create(d, &r);
-        if (rc == RT355_OK) { sc->multi->scenes.push_back(r); sc->multi->devices.push_back(devices[i]); }
+    { // the scene replicated: flattened and uploaded once per device, all devices at once (a thread each: the scene
+      // table of a million triangles takes a second to build, and a thread's current device is its own)
+        std::vector<rt355_scene *> made((size_t)n_devices, nullptr);
+        std::vector<int> rcs((size_t)n_devices, RT355_OK);
+        std::vector<std::string> errs((size_t)n_devices);
+        std::vector<std::thread> threads;
+        for (int i = 0; i < n_devices; i++)
+            threads.emplace_back([&, i] {
+                if (hipSetDevice(devices[i]) != hipSuccess) { (void)hipGetLastError(); rcs[i] = RT355_ERR_DEVICE; errs[i] = "hipSetDevice failed"; return; }
+                rcs[i] = rt355_scene_create(d, &made[i]);
+                if (rcs[i] != RT355_OK) errs[i] = g_err;
+            });
+        for (auto &t : threads) t.join();
+        for (int i = 0; i < n_devices; i++) {
+            if (made[i]) { sc->multi->scenes.push_back(made[i]); sc->multi->devices.push_back(devices[i]); }
+            if (rcs[i] != RT355_OK && rc == RT355_OK) rc = fail(rcs[i], "device " + std::to_string(devices[i]) + ": " + errs[i]);
+        }
     }
     (void)hipSetDevice(before);
     if (rc != RT355_OK) {
