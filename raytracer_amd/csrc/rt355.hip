@@ -578,8 +578,29 @@ __global__ void k_gen_primary(DCamera cam, Frame f, float4 *__restrict__ ray32) 
     rid_to_xy(rid, f.tiles_x, &x, &y);
     float4 out = nan4();
     if (x < f.grid_w && y < f.grid_h) {
-        Ray e = grid_ray(cam, f, x, y);
-        out = make_float4((float)e.npe.x, (float)e.npe.y, (float)e.npe.z, 0.f);
+        // The search record is the fp32 rounding of the unit direction and only has to be within ~1e-9 of it (the
+        // searches' margins start at 2^-25): the point on the image plane as CalcView computes it, then ONE
+        // normalisation by a Newton-refined reciprocal square root instead of CalcView's two correctly rounded ones
+        // (a square root and three divisions each), which the fp64 kernels make when they shade the ray.
+        double x_per, y_per;
+        if (f.alias <= 0) {
+            x_per = (double)x / (double)f.width; y_per = (double)frame_row(f, y) / (double)f.height;
+        } else {
+            const int px = x / f.alias, p = x % f.alias, py = frame_row(f, y / f.alias), q = y % f.alias;
+            x_per = ((rt355x_jitter(f.seed, px, py, q * f.alias + p, 0) + p) / f.alias + px) / (double)f.width;
+            y_per = ((rt355x_jitter(f.seed, px, py, q * f.alias + p, 1) + q) / f.alias + py) / (double)f.height;
+        }
+        const d3 pp = vadd(vadd(ld3(cam.p00), vmul(ld3(cam.n0), x_per * cam.s_x)), vmul(ld3(cam.n1), y_per * cam.s_y));
+        const d3 v = vsub(pp, ld3(cam.p_eye));
+        const double len2 = v.x * v.x + v.y * v.y + v.z * v.z;
+        if (len2 > 1e-200 && len2 < 1e200) {
+            double r = __builtin_amdgcn_rsq(len2);
+            r = fma(r * 0.5, fma(-len2 * r, r, 1.0), r);
+            out = make_float4((float)(v.x * r), (float)(v.y * r), (float)(v.z * r), 0.f);
+        } else { // (a degenerate camera: the reference's own operations)
+            const Ray e = grid_ray(cam, f, x, y);
+            out = make_float4((float)e.npe.x, (float)e.npe.y, (float)e.npe.z, 0.f);
+        }
     }
     ray32[rid] = out;
 }
