@@ -2186,7 +2186,17 @@ template <bool SOFT = false, bool SKIP = false, class Occluder>
 __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, const HitRec &h, uint32_t sum,
                                                 Occluder occluder, uint32_t &n_shadow, double soft_m = 0, double soft_n = 0) {
     const DLight &L = sh.lights[k];
-    const d3 nhl = light_nhl(L, h.ph);
+    // nhl of shader.h:75-82, and with it |ph - position|: CalcShadow's L = |position - ph| (shader.h:412) is the same
+    // double (the components are negated exactly, so the squares and their sum are the same), one square root saved
+    d3 nhl;
+    double dist = 0;
+    if (L.type == 0) {
+        nhl = ld3(L.direction);
+    } else {
+        nhl = vsub(h.ph, ld3(L.position));
+        dist = vlen(nhl);
+        if (dist != 0) nhl = vdiv(nhl, dist); // Normalize, vector3D.h:79-88
+    }
     uint32_t clr = calc_diffuse(L, h.cm0, h.cm1, h.nh, nhl);
     clr = calc_specular<SKIP>(sh, L, clr, h.reh, nhl);
     if (!h.no_border) clr = calc_border(sh, clr, h.border_w);
@@ -2198,7 +2208,7 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
         const d3 nlh = vsub(pl, h.ph);                                                                      // :445
         if (!(dot(h.nh, nlh) <= 0)) {
             const double t_min = occluder(mkview(h.ph, nlh));                                               // :454
-            const double Ld = vlen(vsub(ld3(L.position), h.ph));                                            // :462
+            const double Ld = L.type != 0 ? dist : vlen(vsub(ld3(L.position), h.ph));                       // :462
             shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
             n_shadow += 1;
         }
@@ -2207,7 +2217,7 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
         if (L.type == 0) { sr.pe = h.ph; sr.npe = ld3(L.shadow_dir); }
         else sr = mkview(h.ph, vmul(nhl, -1));
         const double t_min = occluder(sr);
-        const double Ld = vlen(vsub(ld3(L.position), h.ph)); // shader.h:412
+        const double Ld = L.type != 0 ? dist : vlen(vsub(ld3(L.position), h.ph)); // shader.h:412
         shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
         n_shadow += 1;
     }
