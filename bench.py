@@ -902,7 +902,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=0, help="pixel stride of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--in-flight", type=int, default=2, help="sweep workloads: frames in flight per rank (scene handles)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="sweep workloads: scene handles per rank, each sweeping its share of the frames from a host thread of its own "
+                         "(one handle keeps two frames in flight by itself)")
     ap.add_argument("--inproc", action="store_true",
                     help="N > 1 through ONE process that drives all N GPUs (rt355_scene_create_multi) instead of one rank per GPU")
     ap.add_argument("--no-inproc", action="store_true", help="N > 1: do not measure the one-process way beside the ranks' own")

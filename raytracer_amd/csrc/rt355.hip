@@ -3453,6 +3453,21 @@ static Knobs knobs_from_environment() {
     return k;
 }
 
+// What the host keeps per frame in flight: the timing events, the page-locked copy of the counters, and what
+// rt355_scene_sync needs to turn them into the caller's statistics.
+struct FrameBook {
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_done = nullptr; // ev_done: the counters have reached host_counters
+    unsigned long long *host_counters = nullptr; // pinned copy of Work::counters, filled by the frame's last command
+    std::vector<hipEvent_t> ev_search;  // begin/end pairs
+    std::vector<hipEvent_t> ev_resolve; // begin/end pairs
+    int resolve_launches = 0, search_launches = 0;
+    std::vector<std::pair<int, int>> launch_choice; // (kind of launch, rays per lane) per search launch
+    rt355_stats *pending_stats = nullptr;
+    hipStream_t pending_stream = nullptr;
+    uint64_t pending_primary = 0;
+    int pending_nprims = 0;
+    bool pending = false;
+};
 struct MultiScene;
 struct rt355_scene {
     MultiScene *multi = nullptr; // rt355_scene_create_multi: this handle only deals calls to one scene per device
@@ -3480,21 +3495,19 @@ struct rt355_scene {
     GeneralTable general{};                     // scene table for mirror rays (reflective scenes that are searched)
     bool has_general = false;
     double ks_abs_max = 0;                      // largest |ks| of the scene
-    // timing / stats of the outstanding render
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_done = nullptr; // ev_done: the counters have reached host_counters
-    unsigned long long *host_counters = nullptr; // pinned copy of Work::counters, filled by the frame's last command
-    std::vector<hipEvent_t> ev_search; // begin/end pairs
-    std::vector<hipEvent_t> ev_resolve; // begin/end pairs
-    int resolve_launches = 0;
+    // timing / stats of the outstanding render: two sets, so that a sweep can enqueue frame i + 1 while frame i still
+    // runs (it waits for the statistics of frame i - 1 only); every other caller uses set 0 alone
+    FrameBook book[2];
+    int cur = 0; // the set the next enqueue uses
+    FrameBook &bk() { return book[cur]; }
     double resolve_ms = 0;
-    int search_launches = 0;
     double search_ms = 0;
+    int last_search_launches = 0, last_resolve_launches = 0; // of the frame synced last
     std::vector<double> launch_ms, resolve_launch_ms;
     // packet size per kind of search launch (0 camera rays, 1 lights with a position, 2 directional lights):
     // best time seen with 4 and with 1 ray per lane (< 0 = not tried yet), and what each launch of the
     // outstanding frame used
     double tune_ms[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
-    std::vector<std::pair<int, int>> launch_choice; // (kind of launch, rays per lane) per search launch
     // rt355_render (host pixmap): the device framebuffer kept from call to call, the stream the readback runs on
     // beside the rendering of the next part of the frame, and page-locked staging for pixmaps that are pageable
     unsigned char *fb = nullptr; size_t fb_bytes = 0;
@@ -3510,11 +3523,6 @@ struct rt355_scene {
     double readback_ms[2][3] = {{0, 0, 0}, {0, 0, 0}}; // ... what the last three calls took each way: [0] direct, [1] copied in parts (ms of wall time)
     uint32_t readback_calls[2] = {0, 0};                // ... and how many calls went each way
     std::vector<hipEvent_t> ev_copy, ev_part; // per part of a frame: its rows have arrived / have been rendered
-    rt355_stats *pending_stats = nullptr;
-    hipStream_t pending_stream = nullptr;
-    uint64_t pending_primary = 0, pending_pairs_static = 0;
-    int pending_nprims = 0;
-    bool pending = false;
 };
 
 // One scene on several GPUs of this process (rt355_scene_create_multi, below): a scene and a host thread per device.
@@ -3940,10 +3948,12 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     sc->view.far_origin = std::min(FAR_ORIGIN, FAR_SCALE * (1.0 + extent + rmax));
     if (sc->view.n_prims >= SEARCH_MIN_PRIMS && (rc = build_general_table(sc, objs, tris, prim_obj, prim_tri)))
         return rc;
-    HIP_TRY(hipEventCreate(&sc->ev_begin));
-    HIP_TRY(hipEventCreate(&sc->ev_end));
-    HIP_TRY(hipEventCreate(&sc->ev_done));
-    HIP_TRY(hipHostMalloc((void **)&sc->host_counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
+    for (FrameBook &b : sc->book) {
+        HIP_TRY(hipEventCreate(&b.ev_begin));
+        HIP_TRY(hipEventCreate(&b.ev_end));
+        HIP_TRY(hipEventCreate(&b.ev_done));
+        HIP_TRY(hipHostMalloc((void **)&b.host_counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
+    }
     void *ctr = nullptr;
     HIP_TRY(hipMalloc(&ctr, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     sc->owned.push_back(ctr);
@@ -3951,9 +3961,9 @@ extern "C" int rt355_scene_create(const rt355_scene_desc *d, rt355_scene **out) 
     for (int i = 0; i < 2; i++) { // the event pairs every frame needs (frames with more launches add theirs in ensure_work)
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
-        sc->ev_search.push_back(e);
+        sc->book[0].ev_search.push_back(e);
         HIP_TRY(hipEventCreate(&e));
-        sc->ev_resolve.push_back(e);
+        sc->book[0].ev_resolve.push_back(e);
     }
     return RT355_OK;
     };
@@ -4012,17 +4022,20 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
         fprintf(stderr, "\n");
     }
     (void)hipSetDevice(sc->device);
-    if (sc->pending && sc->pending_stream != nullptr) (void)hipStreamSynchronize(sc->pending_stream);
-    else (void)hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     free_work(sc);
     for (void *p : sc->owned) (void)hipFree(p);
     free_tables(sc);
     if (sc->d_lights) (void)hipFree(sc->d_lights);
     if (sc->d_dirs) (void)hipFree(sc->d_dirs);
-    if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
-    if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
-    if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
-    if (sc->host_counters) (void)hipHostFree(sc->host_counters);
+    for (FrameBook &b : sc->book) {
+        if (b.ev_begin) (void)hipEventDestroy(b.ev_begin);
+        if (b.ev_end) (void)hipEventDestroy(b.ev_end);
+        if (b.ev_done) (void)hipEventDestroy(b.ev_done);
+        if (b.host_counters) (void)hipHostFree(b.host_counters);
+        for (hipEvent_t e : b.ev_search) (void)hipEventDestroy(e);
+        for (hipEvent_t e : b.ev_resolve) (void)hipEventDestroy(e);
+    }
     if (sc->copy_stream) { (void)hipStreamSynchronize(sc->copy_stream); (void)hipStreamDestroy(sc->copy_stream); }
     if (sc->copy_stream2) { (void)hipStreamSynchronize(sc->copy_stream2); (void)hipStreamDestroy(sc->copy_stream2); }
     if (sc->sweep_stream) { (void)hipStreamSynchronize(sc->sweep_stream); (void)hipStreamDestroy(sc->sweep_stream); }
@@ -4031,8 +4044,6 @@ extern "C" void rt355_scene_destroy(rt355_scene *sc) {
     if (sc->stage) (void)hipHostFree(sc->stage);
     for (hipEvent_t e : sc->ev_copy) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->ev_part) (void)hipEventDestroy(e);
-    for (hipEvent_t e : sc->ev_search) (void)hipEventDestroy(e);
-    for (hipEvent_t e : sc->ev_resolve) (void)hipEventDestroy(e);
     delete sc;
 }
 
@@ -4046,10 +4057,13 @@ static int slots_for(uint32_t n_rays, int n_lights) {
     return slots;
 }
 
+static int sync_book(rt355_scene *sc, FrameBook &bk);
+static bool any_pending(const rt355_scene *sc) { return sc->book[0].pending || sc->book[1].pending; }
 // n_rays: the rays of the frame being enqueued (the strides follow it); cap_rays >= n_rays: what the workspace must
 // hold without growing again (the largest part of a frame that is enqueued in parts).
 static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundles, int n_groups, uint32_t cap_rays_wanted = 0) {
     if (slots + 1 > sc->table_slots) { // one set of bundle tables per light in flight + one for the camera rays
+        if (any_pending(sc)) { int rc = rt355_scene_sync(sc); if (rc) return rc; } // (a sweep's frame before this one may still run)
         free_tables(sc);
         Tables &t = sc->tables;
         const size_t sets = (size_t)slots + 1;
@@ -4069,15 +4083,15 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
         memset(&none, 0, sizeof none);
         sc->built.assign(sets, none);
     }
-    while ((int)sc->ev_search.size() < 2 * n_bundles) {
+    while ((int)sc->bk().ev_search.size() < 2 * n_bundles) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
-        sc->ev_search.push_back(e);
+        sc->bk().ev_search.push_back(e);
     }
-    while ((int)sc->ev_resolve.size() < 2 * (1 + n_groups)) {
+    while ((int)sc->bk().ev_resolve.size() < 2 * (1 + n_groups)) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
-        sc->ev_resolve.push_back(e);
+        sc->bk().ev_resolve.push_back(e);
     }
     Work &w = sc->work;
     cap_rays_wanted = std::max(cap_rays_wanted, n_rays);
@@ -4090,6 +4104,7 @@ static int ensure_work(rt355_scene *sc, uint32_t n_rays, int slots, int n_bundle
     }
     const uint32_t cap_rays = std::max(cap_rays_wanted, sc->work_rays);
     const int cap_slots = std::max(slots, sc->work_slots);
+    if (any_pending(sc)) { int rc = rt355_scene_sync(sc); if (rc) return rc; } // (a sweep's frame before this one may still run)
     free_work(sc);
     const size_t n = cap_rays, g = (size_t)cap_slots;
     HIP_TRY(hipMalloc((void **)&w.rec_d, 10 * n * sizeof(double)));
@@ -4223,7 +4238,8 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     const bool soft = opts->shading == RT355_SHADING_SOFT;
     const bool lit = soft || opts->shading == RT355_SHADING_LIGHTS; // CalcSubPixel with Shader::shading (not CalcSubPixel2)
     HIP_TRY(hipSetDevice(sc->device));
-    if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
+    // (the set of the bookkeeping this frame uses must be free; a sweep's other set may still hold the frame before)
+    if (sc->bk().pending) { int rc = sync_book(sc, sc->bk()); if (rc) return rc; }
     hipStream_t st = (hipStream_t)hip_stream;
     if (rows.count == 0 && part.first && part.last) { // a share without tiles (more shares than the slab has tiles): nothing to render
         if (stats) memset(stats, 0, sizeof *stats);
@@ -4371,9 +4387,9 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     }
     const Work &w = noalloc ? w_noalloc : sc->work;
     if (part.first) {
-        HIP_TRY(hipEventRecord(sc->ev_begin, st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_begin, st));
         HIP_TRY(hipMemsetAsync(w.counters, 0, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long), st));
-        sc->pending_primary = 0;
+        sc->bk().pending_primary = 0;
     }
     if (!(part.first && part.last) && can_search)
         return fail(RT355_ERR_ARG, "internal: only a frame that one kernel renders is enqueued in parts");
@@ -4384,7 +4400,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     const unsigned n_tiles = (unsigned)(f.tiles_x * f.tiles_y);
     unsigned char *pix = (unsigned char *)d_pixmap;
     int launches = 0;
-    sc->launch_choice.clear();
+    sc->bk().launch_choice.clear();
     // rays per lane for a kind of launch: try 4, then 1, then keep the faster
     auto packet_rays_for = [&](int cls) -> int {
         if (sc->knobs.packet_rays) return (int)sc->knobs.packet_rays;
@@ -4398,10 +4414,10 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
                              uint32_t total_stride, bool spill_cleared = false) -> int {
         for (int i = 0; i < sl.count && !spill_cleared; i++) // empty spill lists for the bundles of this launch
             HIP_TRY(hipMemsetAsync(w.spill.count + sl.slot[i], 0, sizeof(uint32_t), st));
-        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches], st));
         if (opts->mode == RT355_MODE_PACKET) {
             const int cls = list ? kind : 0, pr = packet_rays_for(cls);
-            sc->launch_choice.push_back({cls, pr});
+            sc->bk().launch_choice.push_back({cls, pr});
             const size_t n_entries = list ? (size_t)w.list_stride : (size_t)f.n_rays, per_block = (size_t)PACKET_THREADS * pr;
             const dim3 grid((unsigned)((n_entries + per_block - 1) / per_block), (unsigned)sl.count);
             // the search, then the waves that share what its longest waves handed over (blocks past the list's end leave at once)
@@ -4425,14 +4441,14 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             else LAUNCH_PACKET(2, 1);
 #undef LAUNCH_PACKET
         } else {
-            sc->launch_choice.push_back({-1, 0});
+            sc->bk().launch_choice.push_back({-1, 0});
             const dim3 grid(n_tiles, (unsigned)sl.count);
             if (kind == 1)
                 hipLaunchKernelGGL(k_search<1>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride);
             else
                 hipLaunchKernelGGL(k_search<2>, grid, dim3(SEARCH_THREADS), 0, st, sc->tables, sc->n_padded, w.ray32, f.n_rays, list, total, w.cand, w.cand_cnt, w.counters, w.spill, sl, w.list_stride, total_stride);
         }
-        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches + 1], st));
         launches++;
         return RT355_OK;
     };
@@ -4511,7 +4527,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         return RT355_OK;
     };
     if (!can_search) { // nothing to search: the whole pixel in one kernel
-        if (part.first) HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
+        if (part.first) HIP_TRY(hipEventRecord(sc->bk().ev_resolve[0], st));
         const Gather ga{sc->d_dirs, sc->n_dirs};
         const SceneView &v = sc->view;
         const bool few = v.n_planes <= GATHER_FEW && v.n_spheres <= GATHER_FEW && v.n_planes + v.n_spheres == v.n_prims &&
@@ -4541,7 +4557,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             if (sc->view.n_envs + sc->view.n_quadrics > 0) LAUNCH_DIRECT(false, true); else LAUNCH_DIRECT(false, false);
         }
 #undef LAUNCH_DIRECT
-        if (part.last) HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
+        if (part.last) HIP_TRY(hipEventRecord(sc->bk().ev_resolve[1], st));
     }
     int resolves = 0;
     // The last stage in parts (see TailParts): part p covers tile rows [tiles_y p / n, tiles_y (p + 1) / n).  Not for
@@ -4600,7 +4616,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             }
         } else {
             HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
-            HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
+            HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches], st));
             Slots one{}; // the mirror rays of this level, compacted (slot 0's lists)
             one.count = 1;
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, one);
@@ -4608,15 +4624,15 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
             hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
                                w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters, w.lvl_live + L);
-            HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st));
-            sc->launch_choice.push_back({-1, 0});
+            HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches + 1], st));
+            sc->bk().launch_choice.push_back({-1, 0});
             launches++;
         }
         Group cur = group_of(0);
         int rc1 = clear_bins(cur);
         if (rc1) return rc1;
         HIP_TRY(hipMemsetAsync(w.far_n, 0, sizeof(uint32_t), st)); // (the far hits of this level: listed by the kernel below)
-        HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_resolve[2 * resolves], st));
         {
             const int brute_l = (L == 0 && !bundles[0].kind) ? 1 : 0;
             const bool env = sc->view.n_envs + sc->view.n_quadrics > 0;
@@ -4625,13 +4641,13 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             else { if (env) LAUNCH_RESOLVE(false, true); else LAUNCH_RESOLVE(false, false); }
 #undef LAUNCH_RESOLVE
         }
-        HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_resolve[2 * resolves + 1], st));
         resolves++;
         for (int j = 0; j < n_groups; j++) {
             if ((rc1 = search_group(cur))) return rc1;
             Group next = group_of(j + 1);
             if ((rc1 = clear_bins(next))) return rc1;
-            HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves], st));
+            HIP_TRY(hipEventRecord(sc->bk().ev_resolve[2 * resolves], st));
             hipLaunchKernelGGL(k_shade_far, dim3(std::min(per_ray_blocks, 2048u)), dim3(256), 0, st, sc->view, sh, fl, w, cur);
             // the frame's last shading launch goes part by part when the caller reads the parts back meanwhile (the
             // time recorded for it then includes the parts' folds and k_average launches)
@@ -4659,7 +4675,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             for (int turn = 0; in_parts && !shade_in_parts && turn < tail_parts; turn++)
                 if ((rc1 = tail_finish(tail_part_of_turn(turn), turn == tail_parts - 1))) return rc1;
             if (in_parts) tail_done = true;
-            HIP_TRY(hipEventRecord(sc->ev_resolve[2 * resolves + 1], st));
+            HIP_TRY(hipEventRecord(sc->bk().ev_resolve[2 * resolves + 1], st));
             resolves++;
             cur = next;
         }
@@ -4686,21 +4702,21 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         }
         Group none;
         memset(&none, 0, sizeof none);
-        HIP_TRY(hipEventRecord(sc->ev_resolve[0], st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_resolve[0], st));
         hipLaunchKernelGGL((k_resolve_primary<true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, no_lights, dc, fl, w,
                            bundles[0].kind ? 0 : 1, none, pix);
-        HIP_TRY(hipEventRecord(sc->ev_resolve[1], st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_resolve[1], st));
         resolves = 1;
         const Gather ga{sc->d_dirs, sc->n_dirs};
         const int walk_blocks = (int)sc->knobs.walk_blocks; // waves that stay, four to a workgroup: several times what the chip holds at once, so that the last ones even out
         if ((rc = ensure_gather(sc, (size_t)(sc->n_dirs + 63) / 64))) return rc; // (w refers to sc->work)
         hipLaunchKernelGGL(k_gather_init, dim3(per_ray_blocks), dim3(256), 0, st, f, w, ga);
         const bool bleed = opts->shading == RT355_SHADING_BLEED;
-        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches], st));
+        HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches], st));
         if (bleed) hipLaunchKernelGGL(k_gather_walk<true>, dim3((unsigned)walk_blocks), dim3(256), 0, st, sc->general, sc->view, f, w, ga);
         else hipLaunchKernelGGL(k_gather_walk<false>, dim3((unsigned)walk_blocks), dim3(256), 0, st, sc->general, sc->view, f, w, ga);
-        HIP_TRY(hipEventRecord(sc->ev_search[2 * launches + 1], st)); // all passes as one entry of the search times
-        sc->launch_choice.push_back({-1, 0});
+        HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches + 1], st)); // all passes as one entry of the search times
+        sc->bk().launch_choice.push_back({-1, 0});
         launches++;
         if (bleed) hipLaunchKernelGGL(k_gather_finish<true>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, f, w, ga, pix);
         else hipLaunchKernelGGL(k_gather_finish<false>, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, f, w, ga, pix);
@@ -4718,18 +4734,18 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
     if (tail && !tail_done && (rc = tail->copy_rows(0, f.rows))) return rc; // (a frame whose last stage is one launch: all rows at once)
     HIP_TRY(hipGetLastError());
-    sc->pending_primary += (uint64_t)f.grid_w * (uint64_t)f.grid_h;
+    sc->bk().pending_primary += (uint64_t)f.grid_w * (uint64_t)f.grid_h;
     if (!part.last) return RT355_OK;
-    HIP_TRY(hipEventRecord(sc->ev_end, st));
-    HIP_TRY(hipMemcpyAsync(sc->host_counters, w.counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long),
+    HIP_TRY(hipEventRecord(sc->bk().ev_end, st));
+    HIP_TRY(hipMemcpyAsync(sc->bk().host_counters, w.counters, COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(sc->ev_done, st));
-    sc->pending = true;
-    sc->pending_stats = stats;
-    sc->pending_stream = st;
-    sc->pending_nprims = sc->view.n_prims;
-    sc->search_launches = launches;
-    sc->resolve_launches = can_search ? resolves : 1;
+    HIP_TRY(hipEventRecord(sc->bk().ev_done, st));
+    sc->bk().pending = true;
+    sc->bk().pending_stats = stats;
+    sc->bk().pending_stream = st;
+    sc->bk().pending_nprims = sc->view.n_prims;
+    sc->bk().search_launches = launches;
+    sc->bk().resolve_launches = can_search ? resolves : 1;
     return RT355_OK;
 }
 
@@ -4746,34 +4762,33 @@ extern "C" int rt355_render_device_noalloc(rt355_scene *sc, const rt355_camera *
     return render_enqueue(sc, cam, shader, opts, d_pixmap, hip_stream, stats, true);
 }
 
-extern "C" int rt355_scene_sync(rt355_scene *sc) {
-    if (!sc) return fail(RT355_ERR_ARG, "rt355_scene_sync: null scene");
-    if (sc->multi) return RT355_OK; // (its calls return when the frame is in the caller's memory)
-    if (!sc->pending) return RT355_OK;
+// Wait for the frame of one set of the bookkeeping and turn its counters and events into the caller's statistics.
+static int sync_book(rt355_scene *sc, FrameBook &bk) {
+    if (!bk.pending) return RT355_OK;
     HIP_TRY(hipSetDevice(sc->device));
-    HIP_TRY(hipEventSynchronize(sc->ev_done));
-    sc->pending = false;
-    const unsigned long long *shards = sc->host_counters;
+    HIP_TRY(hipEventSynchronize(bk.ev_done));
+    bk.pending = false;
+    const unsigned long long *shards = bk.host_counters;
     unsigned long long ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < COUNTER_SHARDS; i++)
         for (int j = 0; j < 8; j++) ctr[j] += shards[i * COUNTER_STRIDE + j];
     unsigned long long too_deep = 0;
     for (int i = 0; i < COUNTER_SHARDS; i++) too_deep += shards[i * COUNTER_STRIDE + 14];
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
+    HIP_TRY(hipEventElapsedTime(&ms, bk.ev_begin, bk.ev_end));
     sc->search_ms = 0;
-    sc->launch_ms.assign(sc->search_launches, 0.0);
-    for (int i = 0; i < sc->search_launches; i++) {
+    sc->launch_ms.assign(bk.search_launches, 0.0);
+    for (int i = 0; i < bk.search_launches; i++) {
         float m = 0;
-        HIP_TRY(hipEventElapsedTime(&m, sc->ev_search[2 * i], sc->ev_search[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&m, bk.ev_search[2 * i], bk.ev_search[2 * i + 1]));
         sc->search_ms += m;
         sc->launch_ms[i] = m;
     }
     { // what this frame's packet launches cost, per kind of launch (a frame can have several groups of lights)
         double sum[3][2] = {{0, 0}, {0, 0}, {0, 0}};
         bool used[3][2] = {{false, false}, {false, false}, {false, false}};
-        for (int i = 0; i < sc->search_launches && i < (int)sc->launch_choice.size(); i++) {
-            const int cls = sc->launch_choice[i].first, which = sc->launch_choice[i].second == 4 ? 0 : 1;
+        for (int i = 0; i < bk.search_launches && i < (int)bk.launch_choice.size(); i++) {
+            const int cls = bk.launch_choice[i].first, which = bk.launch_choice[i].second == 4 ? 0 : 1;
             if (cls < 0) continue;
             sum[cls][which] += sc->launch_ms[i];
             used[cls][which] = true;
@@ -4783,17 +4798,19 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
                 if (used[c][k]) sc->tune_ms[c][k] = sum[c][k];
     }
     sc->resolve_ms = 0;
-    sc->resolve_launch_ms.assign(sc->resolve_launches, 0.0);
-    for (int i = 0; i < sc->resolve_launches; i++) {
+    sc->resolve_launch_ms.assign(bk.resolve_launches, 0.0);
+    for (int i = 0; i < bk.resolve_launches; i++) {
         float m = 0;
-        HIP_TRY(hipEventElapsedTime(&m, sc->ev_resolve[2 * i], sc->ev_resolve[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&m, bk.ev_resolve[2 * i], bk.ev_resolve[2 * i + 1]));
         sc->resolve_ms += m;
         sc->resolve_launch_ms[i] = m;
     }
     sc->last_ms = ms;
-    if (sc->pending_stats) {
-        rt355_stats *s = sc->pending_stats;
-        s->primary_rays = sc->pending_primary;
+    sc->last_search_launches = bk.search_launches;
+    sc->last_resolve_launches = bk.resolve_launches;
+    if (bk.pending_stats) {
+        rt355_stats *s = bk.pending_stats;
+        s->primary_rays = bk.pending_primary;
         s->shadow_rays = ctr[0];
         s->exact_tests = ctr[1];
         s->overflow_rays = ctr[2];
@@ -4817,11 +4834,20 @@ extern "C" int rt355_scene_sync(rt355_scene *sc) {
     return RT355_OK;
 }
 
+extern "C" int rt355_scene_sync(rt355_scene *sc) {
+    if (!sc) return fail(RT355_ERR_ARG, "rt355_scene_sync: null scene");
+    if (sc->multi) return RT355_OK; // (its calls return when the frame is in the caller's memory)
+    // the older frame first: after a sweep the set the next enqueue would use holds it
+    const int rc_old = sync_book(sc, sc->book[sc->cur]);
+    const int rc_new = sync_book(sc, sc->book[sc->cur ^ 1]);
+    return rc_old != RT355_OK ? rc_old : rc_new;
+}
+
 extern "C" int rt355_scene_search_kernel_ms(rt355_scene *sc, double *ms_sum, int32_t *launches) {
     if (sc && sc->multi) return rt355_scene_search_kernel_ms(sc->multi->scenes[0], ms_sum, launches); // (the first device's share)
     if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
     *ms_sum = sc->search_ms;
-    *launches = sc->search_launches;
+    *launches = sc->last_search_launches;
     return RT355_OK;
 }
 
@@ -4830,7 +4856,7 @@ extern "C" int rt355_scene_resolve_kernel_ms(rt355_scene *sc, double *ms_sum, in
     if (sc && sc->multi) return rt355_scene_resolve_kernel_ms(sc->multi->scenes[0], ms_sum, launches); // (the first device's share)
     if (!sc || !ms_sum || !launches) return fail(RT355_ERR_ARG, "null argument");
     *ms_sum = sc->resolve_ms;
-    *launches = sc->resolve_launches;
+    *launches = sc->last_resolve_launches;
     return RT355_OK;
 }
 
@@ -4901,13 +4927,13 @@ static int ensure_readback(rt355_scene *sc) {
         // The runtime grows what it keeps per transfer in flight the first time a process has had some dozens of them
         // (one call of 6 ms somewhere among a handle's first ten frames, measured); a burst of small transfers between
         // events, as a frame's parts make them, has that happen here, in the call that sets the handle up anyway.
-        if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; } // (host_counters is the burst's target)
+        if (any_pending(sc)) { int rc = rt355_scene_sync(sc); if (rc) return rc; } // (host_counters is the burst's target)
         const int n = 96;
         for (int i = 0; i < n; i++) {
             hipStream_t cs = (i & 1) ? sc->copy_stream2 : sc->copy_stream;
             HIP_TRY(hipEventRecord(sc->ev_part[i % RENDER_PARTS_MAX], nullptr));
             HIP_TRY(hipStreamWaitEvent(cs, sc->ev_part[i % RENDER_PARTS_MAX], 0));
-            HIP_TRY(hipMemcpyAsync(sc->host_counters, sc->fb, std::min<size_t>(64, sc->fb_bytes), hipMemcpyDeviceToHost, cs));
+            HIP_TRY(hipMemcpyAsync(sc->bk().host_counters, sc->fb, std::min<size_t>(64, sc->fb_bytes), hipMemcpyDeviceToHost, cs));
             HIP_TRY(hipEventRecord(sc->ev_copy[i % RENDER_PARTS_MAX], cs));
         }
         HIP_TRY(hipStreamSynchronize(sc->copy_stream));
@@ -5103,7 +5129,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
     e = hipStreamSynchronize(sc->copy_stream2);
     if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("readback: ") + hipGetErrorString(e));
-    if (sc->pending) { // the frame's statistics, and what its kernels reported
+    if (any_pending(sc)) { // the frame's statistics, and what its kernels reported
         const int rc_sync = rt355_scene_sync(sc);
         if (rc == RT355_OK) rc = rc_sync;
     }
@@ -5126,7 +5152,7 @@ extern "C" int rt355_render_sweep(rt355_scene *sc, const rt355_camera *cams, int
     Rows rows;
     { int rc0 = rows_of(opts, &rows); if (rc0) return rc0; }
     const size_t row_bytes = (size_t)opts->width * 3, bytes = row_bytes * (size_t)opts->height;
-    if (sc->pending) { int rc0 = rt355_scene_sync(sc); if (rc0) return rc0; }
+    if (any_pending(sc)) { int rc0 = rt355_scene_sync(sc); if (rc0) return rc0; }
     if (bytes > sc->fb_bytes) {
         if (sc->fb) { (void)hipFree(sc->fb); sc->fb = nullptr; sc->fb_bytes = 0; }
         HIP_TRY(hipMalloc((void **)&sc->fb, bytes));
@@ -5173,8 +5199,9 @@ extern "C" int rt355_render_sweep(rt355_scene *sc, const rt355_camera *cams, int
             hipError_t e = hipStreamWaitEvent(st, sc->ev_copy[i & 1], 0);
             if (e != hipSuccess) { rc = fail(RT355_ERR_DEVICE, std::string("rt355_render_sweep: ") + hipGetErrorString(e)); break; }
         }
-        rc = render_enqueue(sc, &cams[i], shader, opts, fb, st, stats ? &stats[i] : nullptr, false); // (waits for frame i - 1's statistics first)
+        rc = render_enqueue(sc, &cams[i], shader, opts, fb, st, stats ? &stats[i] : nullptr, false); // (waits for frame i - 2's statistics first)
         if (rc != RT355_OK) break;
+        sc->cur ^= 1; // frame i + 1 is enqueued while this one runs: it takes the other set of events and counters
         const bool pinned = host_is_pinned(pixmaps[i]);
         if (!pinned && (rc = unstage()) != RT355_OK) break; // the staging memory is free again
         unsigned char *dst = pinned ? pixmaps[i] : sc->stage;
@@ -5188,7 +5215,8 @@ extern "C" int rt355_render_sweep(rt355_scene *sc, const rt355_camera *cams, int
         if (!pinned) staged = i;
     }
     // (on an error too: no transfer into the caller's memory may outlive the call)
-    if (sc->pending) { const int rc_sync = rt355_scene_sync(sc); if (rc == RT355_OK) rc = rc_sync; }
+    if (any_pending(sc)) { const int rc_sync = rt355_scene_sync(sc); if (rc == RT355_OK) rc = rc_sync; }
+    sc->cur = 0;
     if (rc == RT355_OK) rc = unstage();
     hipError_t e = hipStreamSynchronize(sc->copy_stream);
     if (e != hipSuccess && rc == RT355_OK) rc = fail(RT355_ERR_DEVICE, std::string("rt355_render_sweep: ") + hipGetErrorString(e));
@@ -5417,7 +5445,7 @@ extern "C" int rt355_scene_set_option(rt355_scene *sc, const char *name, int64_t
         for (rt355_scene *r : sc->multi->scenes) { const int rc = rt355_scene_set_option(r, name, value); if (rc) return rc; }
         return RT355_OK;
     }
-    if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
+    if (any_pending(sc)) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     const int rc = set_knob(sc->knobs, name, value);
     if (rc == RT355_OK && !strcmp(name, "readback")) sc->readback_key = 0; // (what was timed so far decides nothing any more)
     if (rc == RT355_OK && !strcmp(name, "debug_readback") && value) sc->debug_series.reserve(4096);
@@ -5431,7 +5459,7 @@ extern "C" int rt355_scene_set_directions(rt355_scene *sc, const double *xyz, in
         return RT355_OK;
     }
     HIP_TRY(hipSetDevice(sc->device));
-    if (sc->pending) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
+    if (any_pending(sc)) { int rc = rt355_scene_sync(sc); if (rc) return rc; }
     if (sc->d_dirs) { (void)hipFree(sc->d_dirs); sc->d_dirs = nullptr; }
     sc->n_dirs = 0;
     if (n) {
