@@ -2400,15 +2400,52 @@ __device__ __forceinline__ void closest_hit_walk(const SceneView &s, const Gener
 // (three waves per SIMD: at the two the compiler picks by itself the frame takes 30 % longer, at four the spills cost more)
 // WALK: a scene of many primitives -- every ray of the pixel's tree, shadow rays included, finds its candidates
 // through the scene table (closest_hit_walk) instead of testing every primitive.
-template <bool SOFT, bool WALK>
+// The rays of a frame whose first call of CalcSubPixel has children -- the object hit (objs[0] after a miss,
+// main.cpp:94,116) has ks >= 0.05 (times = 1 and ktotal = ks after the first call, main.cpp:97-103) or is of glass --
+// listed for k_render_refract<.., CHILDREN> (the list and its count share the far hits' arrays, free by then).
+__global__ __launch_bounds__(256) void k_list_children(SceneView s, Frame f, Work w) {
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool has = false;
+    if (rid < f.n_rays && s.n_objects > 0) {
+        const int obj = w.rec_obj[rid];
+        if (obj != -2) {
+            const DObject &o = s.objects[obj >= 0 ? obj : 0];
+            has = (o.ks >= 0.05) || (o.fresnel < 1);
+        }
+    }
+    const unsigned long long m = __ballot(has);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(w.far_n, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (has) w.far_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rid;
+}
+// CHILDREN: a searched scene with glass in it is rendered in two steps.  The frame's own pipeline (packet search,
+// k_resolve_primary, the light groups) does what every pixel needs -- the camera ray's closest hit and its shading
+// with searched shadow rays -- and leaves hit record and colour in the workspace; this kernel then runs over the rays
+// of the frame (one thread per rid) and, for the few whose first call of CalcSubPixel has children (an object with
+// ks or glass at the hit, or objs[0]'s after a miss: main.cpp:94,116), takes the recursion up from there: the first
+// call's closest hit and shading are read, not computed, and every later ray of the pixel's tree walks the scene table
+// as before.  The other rays keep the colour they have.
+template <bool SOFT, bool WALK, bool CHILDREN = false>
 __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
                                                         GeneralTable table, unsigned char *__restrict__ pixmap) {
     uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0, n_deep = 0, n_pairs = 0;
-    int x, y;
-    direct_xy(f, &x, &y);
-    const bool valid = x < f.grid_w && y < f.grid_h;
-    const uint32_t rid = (WALK && valid) ? xy_to_rid(x, y, f.tiles_x) : 0u; // the thread's slots of the per-ray lists
+    int x = 0, y = 0;
+    uint32_t rid_c = 0u;
+    bool listed = false;
+    if (CHILDREN) { // the rays k_list_children found, one per thread: full waves, whatever share of the frame they are
+        const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
+        listed = at < *w.far_n;
+        if (listed) { rid_c = w.far_list[at]; rid_to_xy(rid_c, f.tiles_x, &x, &y); }
+    } else {
+        direct_xy(f, &x, &y);
+    }
+    const bool valid = (!CHILDREN || listed) && x < f.grid_w && y < f.grid_h;
+    const uint32_t rid = CHILDREN ? rid_c : ((WALK && valid) ? xy_to_rid(x, y, f.tiles_x) : 0u); // the thread's slots of the per-ray lists
     uint32_t pixel = 0u;
+    bool changed = !CHILDREN; // CHILDREN: the ray's colour is written only where the recursion went on
     do {
     if (!valid) break;
     Ray e = grid_ray(cam, f, x, y);
@@ -2430,7 +2467,17 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
         d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
         uint32_t own = 0u;
         if (s.n_objects == 0) { value = 0u; break; } // (the reference would read objs[0] of an empty vector)
-        if (outside <= -1) {
+        if (CHILDREN && first) { // the camera ray's call: its hit and its colour are there already
+            const size_t n = f.n_rays;
+            const int obj0 = w.rec_obj[rid];
+            if (obj0 >= 0) {
+                ph = D3(w.rec_d[0 * n + rid], w.rec_d[1 * n + rid], w.rec_d[2 * n + rid]);
+                nh = D3(w.rec_d[3 * n + rid], w.rec_d[4 * n + rid], w.rec_d[5 * n + rid]);
+                oi = obj0;
+            }
+            own = w.rec_sum[rid];
+            changed = true;
+        } else if (outside <= -1) {
             intersect_inside(s, oi, e, outside, &ph, &nh);
         } else {
             Closest c;
@@ -2532,7 +2579,8 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
     }
     pixel = value;
     } while (0);
-    direct_store(pixmap, f, w, x, y, valid, pixel);
+    if (CHILDREN) { if (valid && changed) w.rec_sum[rid] = pixel; } // (k_average writes the pixmap)
+    else direct_store(pixmap, f, w, x, y, valid, pixel);
     block_count<7>(w.counters, {4, 0, 1, 2, 6, 14, 5}, {n_hit, n_shadow, n_eval, n_over, n_secondary, n_deep, WALK ? n_pairs : 0u});
 }
 
@@ -3407,6 +3455,7 @@ struct Knobs {
     int64_t heavy_small_rays = HEAVY_SMALL_RAYS; // a call of at most this many rays (a share of a frame) searches a scene of
                                                // HEAVY_SMALL_PRIMS primitives or more in two launches too, handing over after HEAVY_SMALL_AFTER (0: never)
     int64_t packet_rays = 0;                   // rays per lane of the packet search: 1 or 4 (0: timed on the first frames)
+    int64_t refract_whole = 0;                 // 1: a searched scene with glass is rendered by the one kernel that walks every ray's tree (the former way)
     int64_t gather_general = 0;                // 1: the gather shaders' general kernel also for scenes of a few planes and spheres
     int64_t walk_blocks = 8192;                // workgroups of the searched gather's walk
     int64_t readback = 0;                      // rt355_render into a page-locked pixmap: 0 timed per kind of frame, 1 kernels write it, 2 copied in parts
@@ -3421,7 +3470,7 @@ static const KnobName kKnobs[] = {
     {"heavy_min_prims", &Knobs::heavy_min_prims, 0, INT32_MAX}, {"heavy_after", &Knobs::heavy_after, 1, INT32_MAX},
     {"heavy_workers", &Knobs::heavy_workers, 1, 1024}, {"heavy_small_rays", &Knobs::heavy_small_rays, 0, INT32_MAX},
     {"packet_rays", &Knobs::packet_rays, 0, 4},
-    {"gather_general", &Knobs::gather_general, 0, 1}, {"walk_blocks", &Knobs::walk_blocks, 1, 1 << 20},
+    {"gather_general", &Knobs::gather_general, 0, 1}, {"refract_whole", &Knobs::refract_whole, 0, 1}, {"walk_blocks", &Knobs::walk_blocks, 1, 1 << 20},
     {"readback", &Knobs::readback, 0, 2}, {"render_parts", &Knobs::render_parts, 1, 64}, {"tail_parts", &Knobs::tail_parts, 1, 64},
     {"no_tail_parts", &Knobs::no_tail_parts, 0, 1}, {"tail_bottom_first", &Knobs::tail_bottom_first, 0, 1},
     {"tail_even", &Knobs::tail_even, 0, 1}, {"copy_streams", &Knobs::copy_streams, 1, 2}, {"last_copied", &Knobs::last_copied, 0, 1},
@@ -4207,6 +4256,11 @@ static int ensure_gather(rt355_scene *sc, size_t live_rows) {
 // A frame that one kernel renders can be enqueued as several calls, one per group of rows, that count into the
 // same statistics and are waited for as one: `first` clears the counters and uploads the lights, `last` closes
 // the frame (rt355_render reads every part back while the next one renders).
+// A scene with glass (Shader::shading's renderer) that is searched: rendered in two steps, see k_render_refract<.., CHILDREN>.
+static bool searched_with_glass(const rt355_scene *sc, const rt355_opts *opts) {
+    return sc->refractive && opts->shading == RT355_SHADING_LIGHTS && opts->mode != RT355_MODE_BRUTE && sc->has_general &&
+           sc->view.n_prims >= SEARCH_MIN_PRIMS && !sc->knobs.refract_whole;
+}
 struct PartOfFrame { bool first, last; int max_rows = 0; }; // max_rows: the rows of the frame's largest part (0: this one)
 // How rt355_render takes a searched frame's pixels back while the frame is still being shaded: the last stage of the
 // frame (the shading of the last group of lights, the fold of the mirror levels, k_average) is launched in `n_parts`
@@ -4275,9 +4329,12 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     // refraction (Shader::shading's renderer only: CalcSubPixel2 does not recurse) is rendered unsearched, one
     // thread per pixel walking its whole tree of rays
     const bool refract = sc->refractive && lit;
-    const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
+    // ... unless the scene is searched: then the frame's own pipeline renders every camera ray's hit and shading, and
+    // the kernel that walks the trees takes over only where a first call has children (k_render_refract<.., CHILDREN>)
+    const bool refract_children = refract && searched_with_glass(sc, opts) && !noalloc;
+    const bool can_search = (opts->mode != RT355_MODE_BRUTE) && sc->view.n_prims >= SEARCH_MIN_PRIMS && (!refract || refract_children);
     int extra_levels = 0;
-    if (can_search && sc->reflective && lit) {
+    if (can_search && sc->reflective && lit && !refract) { // (with glass in the scene the trees' own mirror rays are the reflection)
         double k = 1.0;
         while (extra_levels < 3 && (k *= sc->ks_abs_max) >= 0.05) extra_levels++;
     }
@@ -4300,7 +4357,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         if (!na) return fail(RT355_ERR_DEVICE, "rt355_render_device_noalloc: the no-alloc array of this device was not bound");
     } else {
         // search launches: the camera rays and two per group of lights, per level; the gather passes record two pairs
-        const int n_search = std::max((1 + 2 * n_groups) * (1 + extra_levels), gather_searched ? 2 : 1);
+        const int n_search = std::max((1 + 2 * n_groups) * (1 + extra_levels), gather_searched ? 2 : 1) + (refract_children ? 1 : 0);
         rc = ensure_work(sc, f.n_rays, slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1, cap_rays);
         if (rc) return rc;
         if ((levels || gather_searched) && (rc = ensure_levels(sc))) return rc;
@@ -4563,7 +4620,7 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     // The last stage in parts (see TailParts): part p covers tile rows [tiles_y p / n, tiles_y (p + 1) / n).  Not for
     // supersampled frames (a pixel's sub-samples span tile rows), shares of interleaved tiles, or the gather shaders
     // (whose last stage is a blend that costs nothing).
-    const int tail_parts = (tail && can_search && !gather_searched && f.alias == 0 && f.tile_count <= 1)
+    const int tail_parts = (tail && can_search && !gather_searched && !refract_children && f.alias == 0 && f.tile_count <= 1)
                                ? std::max(1, std::min(tail->n_parts, f.tiles_y)) : 1;
     bool tail_done = false;
     // the part of the last turn, whose transfer no kernel overlaps, is half as high as the others
@@ -4729,6 +4786,16 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             if ((rc = run_level(L + 1))) return rc;
         }
         if (levels && !tail_done) hipLaunchKernelGGL(k_fold_levels, dim3(per_ray_blocks), dim3(256), 0, st, f, w, pix);
+        if (refract_children) { // the rays whose first call of CalcSubPixel has children: their trees, from the hit on
+            HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(w.far_n, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches], st));
+            hipLaunchKernelGGL(k_list_children, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w);
+            hipLaunchKernelGGL((k_render_refract<false, true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
+            HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches + 1], st));
+            sc->bk().launch_choice.push_back({-1, 0});
+            launches++;
+        }
     }
     if ((f.alias > 0 || f.deferred) && !tail_done)
         hipLaunchKernelGGL(k_average, dim3((unsigned)((f.width + 255) / 256), (unsigned)f.rows), dim3(256), 0, st, f, w.rec_sum, pix);
@@ -4967,7 +5034,7 @@ extern "C" int rt355_render(rt355_scene *sc, const rt355_camera *cam, const rt35
     { int rc0 = ensure_readback(sc); if (rc0) return rc0; }
     const bool pinned = host_is_pinned(pixmap);
     const bool refract = sc->refractive && (opts->shading == RT355_SHADING_LIGHTS || opts->shading == RT355_SHADING_SOFT);
-    const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && !refract;
+    const bool searched = opts->mode != RT355_MODE_BRUTE && sc->view.n_prims >= SEARCH_MIN_PRIMS && (!refract || searched_with_glass(sc, opts));
     const bool one_kernel = opts->tile_count <= 1 && !searched;
     // a searched frame whose last stage can be launched in parts, each read back while the next is shaded (TailParts)
     const bool tail_way = searched && opts->tile_count <= 1 && opts->alias == 0 && !sc->knobs.no_tail_parts &&
