@@ -62,3 +62,11 @@ def test_null_arguments_are_rejected_without_a_gpu():
     out = ctypes.c_void_p()
     assert L.rt355_scene_create(None, ctypes.byref(out)) == -1
     assert b"null" in L.rt355_last_error()
+    # the entry points added for one process on several GPUs and for the handle's options check their arguments
+    # before they touch the runtime
+    devs = (ctypes.c_int32 * 2)(0, 1)
+    assert L.rt355_scene_create_multi(None, devs, 2, ctypes.byref(out)) == -1
+    assert L.rt355_scene_set_option(None, b"readback", 1) == -1 and b"null" in L.rt355_last_error()
+    assert L.rt355_scene_sync(None) == -1
+    assert L.rt355_render(None, None, None, None, None, None) == -1
+    assert L.rt355_render_sweep(None, None, 0, None, None, None, None) == -1
