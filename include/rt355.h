@@ -399,7 +399,8 @@ double rt355_strata(uint32_t seed, int32_t x, int32_t y, int32_t which);
  *                     primitives or more in two launches too, handing over after 64 (0 = never)
  *   "gather_general"  1 = the gather shaders' general kernel also for scenes of at most four planes and spheres
  *   "refract_whole"   1 = a searched scene with glass in it is rendered by the one kernel that walks every ray's tree
- *                     (default 0: the frame's own pipeline renders every camera ray's hit, the trees start from there)
+ *                     (default 0: the frame's own pipeline renders every camera ray's hit, the trees start from there);
+ *                     "refract_single" 1 = one lane per tree in that second step instead of four (measurement aid)
  *   "walk_blocks"     workgroups of the searched gather's walk (default 8192)
  *   "gather"          multi-device scenes only: 0 = every GPU writes its rows into the host pixmap (default), 1 = rows
  *                     gathered on the first device and read back from there

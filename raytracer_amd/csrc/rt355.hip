@@ -2317,6 +2317,12 @@ __global__ __launch_bounds__(256, REFLECT ? 3 : 1) void k_render_direct(SceneVie
 // on from the origin with that object's coefficients for ever (main.cpp:94,116) and overflows its stack --
 // so a pixel that fills the stack raises counter 14 and the frame is reported as failed.
 #define REFRACT_OPS 256
+// lanes that share the shadow walks of a listed ray's nodes (k_render_refract<.., CHILDREN, LG>).  Measured on 10 000
+// spheres, a tenth of glass, 8 lights, ms of the second step: 1 lane 2.70, 2 lanes 1.65, 4 lanes 1.62, 8 lanes 1.93 (every
+// lane of a group runs the ray's recursion, so wider groups mean more waves for the same trees)
+#ifndef REFRACT_GROUP
+#define REFRACT_GROUP 4
+#endif
 #define REFRACT_SPAWNS 4
 #define OP_MIRROR 0u  // value = clr * (1 - ks) + child * ks
 #define OP_REFRACT 1u // value = clr * fresnel + child * (1 - fresnel)
@@ -2428,15 +2434,30 @@ __global__ __launch_bounds__(256) void k_list_children(SceneView s, Frame f, Wor
 // ks or glass at the hit, or objs[0]'s after a miss: main.cpp:94,116), takes the recursion up from there: the first
 // call's closest hit and shading are read, not computed, and every later ray of the pixel's tree walks the scene table
 // as before.  The other rays keep the colour they have.
-template <bool SOFT, bool WALK, bool CHILDREN = false>
-__global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w,
+// LG > 1 (CHILDREN only): LG neighbouring lanes stand for one listed ray.  All of them run the ray's recursion, in
+// step and on the same values; where a node is shaded, the walks of its shadow rays -- most of what a node costs, one
+// walk per light that the hit faces -- are dealt to the lanes of the group (light k to lane k mod LG, each lane with
+// workspace slot `lane in group` for its candidates) and the distances handed round with shuffles, so that a node
+// takes the time of two walks instead of one plus one per light.  Lane 0 of a group counts the statistics that are the
+// ray's, every lane those of the shadow walks it made.
+template <bool SOFT, bool WALK, bool CHILDREN = false, int LG = 1>
+__global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w_all,
                                                         GeneralTable table, unsigned char *__restrict__ pixmap) {
     uint32_t n_eval = 0, n_over = 0, n_hit = 0, n_shadow = 0, n_secondary = 0, n_deep = 0, n_pairs = 0;
     int x = 0, y = 0;
     uint32_t rid_c = 0u;
     bool listed = false;
-    if (CHILDREN) { // the rays k_list_children found, one per thread: full waves, whatever share of the frame they are
-        const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sub = LG > 1 ? (threadIdx.x % (uint32_t)LG) : 0u; // the lane's place in its group
+    Work w = w_all;
+    if (LG > 1) { // the lane's own candidate slots: workspace slot `sub`
+        const size_t n = f.n_rays;
+        w.cand = w_all.cand + (size_t)sub * CAND_CAP * n;
+        w.cand_cnt = w_all.cand_cnt + (size_t)sub * n;
+        w.spill.pool = w_all.spill.pool + (size_t)sub * POOL_STRIDE(n);
+        w.spill.count = w_all.spill.count + sub;
+    }
+    if (CHILDREN) { // the rays k_list_children found, one per thread (or group): full waves, whatever share of the frame they are
+        const uint32_t at = (blockIdx.x * blockDim.x + threadIdx.x) / (uint32_t)LG;
         listed = at < *w.far_n;
         if (listed) { rid_c = w.far_list[at]; rid_to_xy(rid_c, f.tiles_x, &x, &y); }
     } else {
@@ -2450,9 +2471,11 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
     if (!valid) break;
     Ray e = grid_ray(cam, f, x, y);
     Spill none; none.pool = nullptr; none.count = nullptr;
-    auto closest = [&](const Ray &ray, Closest &out) {
-        if (WALK) closest_hit_walk<true>(s, table, ray, rid, w, out, n_eval, n_over, n_pairs);
-        else closest_hit(s, ray, true, rid, f.n_rays, nullptr, nullptr, none, out, n_eval, n_over);
+    auto closest = [&](const Ray &ray, Closest &out, bool mine = true) { // mine: this lane counts the walk (LG > 1: the ray's own walks are lane 0's)
+        uint32_t ev = 0, ov = 0, np = 0;
+        if (WALK) closest_hit_walk<true>(s, table, ray, rid, w, out, ev, ov, np);
+        else closest_hit(s, ray, true, rid, f.n_rays, nullptr, nullptr, none, out, ev, ov);
+        if (mine) { n_eval += ev; n_over += ov; n_pairs += np; }
     };
     uint32_t op_clr[REFRACT_OPS], op_what[REFRACT_OPS]; // what = object | kind << 30
     RefractSpawn spawn[REFRACT_SPAWNS];
@@ -2481,18 +2504,44 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
             intersect_inside(s, oi, e, outside, &ph, &nh);
         } else {
             Closest c;
-            closest(e, c);
+            closest(e, c, sub == 0);
             if (c.prim_best >= 0) {
                 if (first) n_hit = 1;
                 const HitRec h = primary_record(s, sh, e, c);
                 ph = h.ph; nh = h.nh; oi = h.obj;
                 if (h.emissive) own = h.cm0;
-                for (int k = 0; !h.emissive && k < sh.n_lights; k++)
-                    own = shade_light<SOFT, true>(sh, k, h, own, [&](const Ray &sr) {
-                        Closest o;
-                        closest(sr, o);
-                        return o.t_best;
-                    }, n_shadow, first ? soft.m : 0.0, first ? soft.n : 0.0);
+                if (LG > 1) {
+                    // LG lights at a time: this lane walks for light k0 + sub (the facing test and the ray as shade_light
+                    // makes them), then the group shades the LG lights in order, each distance read from its lane
+                    const uint32_t lane = threadIdx.x & 63u, group0 = lane - sub;
+                    for (int k0 = 0; !h.emissive && k0 < sh.n_lights; k0 += LG) {
+                        double my_t = RT_FLT_MAX;
+                        const int km = k0 + (int)sub;
+                        if (km < sh.n_lights) {
+                            const DLight &L = sh.lights[km];
+                            const d3 nhl = light_nhl(L, h.ph);
+                            if (!(dot(h.nh, vmul(nhl, -1)) <= 0)) { // shader.h:396
+                                Ray sr;
+                                if (L.type == 0) { sr.pe = h.ph; sr.npe = ld3(L.shadow_dir); }
+                                else sr = mkview(h.ph, vmul(nhl, -1));
+                                Closest o;
+                                closest(sr, o);
+                                my_t = o.t_best;
+                            }
+                        }
+                        for (int j = 0; j < LG && k0 + j < sh.n_lights; j++) {
+                            const double t_j = __shfl(my_t, (int)(group0 + (uint32_t)j), 64);
+                            own = shade_light<SOFT, true>(sh, k0 + j, h, own, [&](const Ray &) { return t_j; }, n_shadow);
+                        }
+                    }
+                } else {
+                    for (int k = 0; !h.emissive && k < sh.n_lights; k++)
+                        own = shade_light<SOFT, true>(sh, k, h, own, [&](const Ray &sr) {
+                            Closest o;
+                            closest(sr, o);
+                            return o.t_best;
+                        }, n_shadow, first ? soft.m : 0.0, first ? soft.n : 0.0);
+                }
             }
         }
         first = false;
@@ -2579,8 +2628,9 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
     }
     pixel = value;
     } while (0);
-    if (CHILDREN) { if (valid && changed) w.rec_sum[rid] = pixel; } // (k_average writes the pixmap)
+    if (CHILDREN) { if (valid && changed && sub == 0) w.rec_sum[rid] = pixel; } // (k_average writes the pixmap)
     else direct_store(pixmap, f, w, x, y, valid, pixel);
+    if (LG > 1 && sub != 0) { n_hit = 0; n_shadow = 0; n_secondary = 0; n_deep = 0; } // (the ray's own: counted by lane 0 of its group)
     block_count<7>(w.counters, {4, 0, 1, 2, 6, 14, 5}, {n_hit, n_shadow, n_eval, n_over, n_secondary, n_deep, WALK ? n_pairs : 0u});
 }
 
@@ -3455,6 +3505,7 @@ struct Knobs {
     int64_t heavy_small_rays = HEAVY_SMALL_RAYS; // a call of at most this many rays (a share of a frame) searches a scene of
                                                // HEAVY_SMALL_PRIMS primitives or more in two launches too, handing over after HEAVY_SMALL_AFTER (0: never)
     int64_t packet_rays = 0;                   // rays per lane of the packet search: 1 or 4 (0: timed on the first frames)
+    int64_t refract_single = 0;                // 1: one lane per listed ray in the second step of such a frame (measurement aid)
     int64_t refract_whole = 0;                 // 1: a searched scene with glass is rendered by the one kernel that walks every ray's tree (the former way)
     int64_t gather_general = 0;                // 1: the gather shaders' general kernel also for scenes of a few planes and spheres
     int64_t walk_blocks = 8192;                // workgroups of the searched gather's walk
@@ -3470,7 +3521,7 @@ static const KnobName kKnobs[] = {
     {"heavy_min_prims", &Knobs::heavy_min_prims, 0, INT32_MAX}, {"heavy_after", &Knobs::heavy_after, 1, INT32_MAX},
     {"heavy_workers", &Knobs::heavy_workers, 1, 1024}, {"heavy_small_rays", &Knobs::heavy_small_rays, 0, INT32_MAX},
     {"packet_rays", &Knobs::packet_rays, 0, 4},
-    {"gather_general", &Knobs::gather_general, 0, 1}, {"refract_whole", &Knobs::refract_whole, 0, 1}, {"walk_blocks", &Knobs::walk_blocks, 1, 1 << 20},
+    {"gather_general", &Knobs::gather_general, 0, 1}, {"refract_whole", &Knobs::refract_whole, 0, 1}, {"refract_single", &Knobs::refract_single, 0, 1}, {"walk_blocks", &Knobs::walk_blocks, 1, 1 << 20},
     {"readback", &Knobs::readback, 0, 2}, {"render_parts", &Knobs::render_parts, 1, 64}, {"tail_parts", &Knobs::tail_parts, 1, 64},
     {"no_tail_parts", &Knobs::no_tail_parts, 0, 1}, {"tail_bottom_first", &Knobs::tail_bottom_first, 0, 1},
     {"tail_even", &Knobs::tail_even, 0, 1}, {"copy_streams", &Knobs::copy_streams, 1, 2}, {"last_copied", &Knobs::last_copied, 0, 1},
@@ -4358,7 +4409,9 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
     } else {
         // search launches: the camera rays and two per group of lights, per level; the gather passes record two pairs
         const int n_search = std::max((1 + 2 * n_groups) * (1 + extra_levels), gather_searched ? 2 : 1) + (refract_children ? 1 : 0);
-        rc = ensure_work(sc, f.n_rays, slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1, cap_rays);
+        // (the trees of a scene with glass deal a node's shadow walks to REFRACT_GROUP lanes, each with a slot of its own)
+        const int alloc_slots = refract_children ? std::max(slots, slots_for(cap_rays, REFRACT_GROUP)) : slots;
+        rc = ensure_work(sc, f.n_rays, alloc_slots, n_search, (1 + n_groups) * (1 + extra_levels) - 1, cap_rays);
         if (rc) return rc;
         if ((levels || gather_searched) && (rc = ensure_levels(sc))) return rc;
     }
@@ -4787,11 +4840,14 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         }
         if (levels && !tail_done) hipLaunchKernelGGL(k_fold_levels, dim3(per_ray_blocks), dim3(256), 0, st, f, w, pix);
         if (refract_children) { // the rays whose first call of CalcSubPixel has children: their trees, from the hit on
-            HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(w.spill.count, 0, LIGHT_GROUP * sizeof(uint32_t), st));
             HIP_TRY(hipMemsetAsync(w.far_n, 0, sizeof(uint32_t), st));
             HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches], st));
             hipLaunchKernelGGL(k_list_children, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w);
-            hipLaunchKernelGGL((k_render_refract<false, true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
+            if (sc->work_slots >= REFRACT_GROUP && !sc->knobs.refract_single) // a group of lanes per listed ray (blocks past the list leave at once)
+                hipLaunchKernelGGL((k_render_refract<false, true, true, REFRACT_GROUP>), dim3(per_ray_blocks * REFRACT_GROUP), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
+            else
+                hipLaunchKernelGGL((k_render_refract<false, true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
             HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches + 1], st));
             sc->bk().launch_choice.push_back({-1, 0});
             launches++;
