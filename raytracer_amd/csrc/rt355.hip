@@ -2890,7 +2890,8 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
     const uint32_t per_pass = (f.n_rays + 63u) / 64u, n_chunks = (uint32_t)ga.n * per_pass, n_waves = gridDim.x * 4u;
     // the wave's place in the pairs (uniform)
     uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
-    uint32_t taken = 0u; // pairs of the chunk already looked at
+    unsigned long long avail = 0ull; // the pairs of the chunk that send a ray and no lane has taken yet
+    bool avail_known = false;
     // a lane's ray and where its walk stands
     bool has = false;
     uint32_t rid = 0u, base = 0u, m = 0u, n_pairs = 0u, n_exact = 0u, n_sent = 0u;
@@ -2933,12 +2934,41 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
     while (true) {
         unsigned long long idle = __ballot(!has);
         while (chunk < n_chunks && (uint32_t)__popcll(idle) >= WALK_REFILL) { // uniform
-            const uint32_t pass = chunk / per_pass, first = (chunk - pass * per_pass) * 64u;
-            const uint32_t mine = taken + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!has && mine < 64u && first + mine < f.n_rays) {
-                const uint32_t r = first + mine;
-                const int i = (int)pass;
-                if ((w.g_live[(size_t)(pass >> 6) * n + r] >> (pass & 63u)) & 1ull) {
+            // First every free lane is given a pair that sends a ray, as long as there are any: the k-th free lane
+            // takes the k-th such pair of the chunk (the pairs' numbers are brought to lanes 0, 1, 2 ... by one
+            // permutation of the wave, and fetched from there), and the next chunk is opened when this one has none
+            // left.  Only then are the rays built, by all the lanes that got one at once: building one takes
+            // hundreds of fp64 instructions, which the whole wave pays for however few of its lanes take part.
+            unsigned long long want = idle;
+            bool got = false;
+            uint32_t got_rid = 0u, got_dir = 0u;
+            while (want != 0ull && chunk < n_chunks) { // uniform
+                const uint32_t pass = chunk / per_pass, first = (chunk - pass * per_pass) * 64u;
+                if (!avail_known) {
+                    const uint32_t r = first + (uint32_t)lane;
+                    avail = __ballot(r < f.n_rays && ((w.g_live[(size_t)(pass >> 6) * n + r] >> (pass & 63u)) & 1ull));
+                    avail_known = true;
+                }
+                if (avail != 0ull) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const bool in_avail = (avail >> lane) & 1ull, wants = (want >> lane) & 1ull;
+                    const uint32_t n_avail = (uint32_t)__popcll(avail), ra = (uint32_t)__popcll(avail & below);
+                    const uint32_t rw = (uint32_t)__popcll(want & below);
+                    // (a permutation of all 64 lanes: the pairs that send a ray first, in order, then the others)
+                    const uint32_t dest = in_avail ? ra : n_avail + ((uint32_t)lane - ra);
+                    const int packed = __builtin_amdgcn_ds_permute((int)(dest * 4u), lane);
+                    const int src = __builtin_amdgcn_ds_bpermute((int)((rw & 63u) * 4u), packed);
+                    const uint32_t n_take = min(n_avail, (uint32_t)__popcll(want));
+                    if (wants && rw < n_take) { got = true; got_rid = first + (uint32_t)src; got_dir = pass; }
+                    avail = __ballot(in_avail && ra >= n_take);
+                    want = __ballot(wants && rw >= n_take);
+                }
+                if (avail == 0ull) { chunk += n_waves; avail_known = false; }
+            }
+            if (got) {
+                const uint32_t r = got_rid;
+                const int i = (int)got_dir;
+                {
                     rid = r;
                     n_sent++;
                     const d3 ray = gather_ray(ga, i, w.lvl_ks[0 * n + rid], w.lvl_ks[1 * n + rid], w.lvl_ks[2 * n + rid], w.lvl_ks[3 * n + rid]);
@@ -2987,8 +3017,6 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
                     }
                 }
             }
-            taken += (uint32_t)__popcll(idle);
-            if (taken >= 64u) { chunk += n_waves; taken = 0u; }
             idle = __ballot(!has);
         }
         if (idle == ~0ull) { // uniform: no lane has a ray
@@ -2996,7 +3024,7 @@ __global__ __launch_bounds__(256, WALK_WAVES) void k_gather_walk(GeneralTable t,
             continue;
         }
 #pragma unroll 1
-        for (int turn = 0; turn < WALK_TURNS; turn++) {
+        for (int step = 0; step < WALK_TURNS; step++) {
             if (!has || held == WALK_HOLD) continue;
             // A turn is priced by its most expensive lane, the one that enters a node, so every lane should enter
             // one: leaves are put among the held ones and finished groups are left on the way, both in a few
@@ -3777,10 +3805,14 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
         for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.c[a]); hi[a] = std::max(hi[a], b.c[a]); }
         prims.push_back(b);
     }
-    // Order: a balanced k-d split of the centres whose cuts fall on the group boundaries of the table -- a range
-    // longer than 4096 is cut at the multiple of 4096 nearest its middle, then at multiples of 64, then of 8 --
-    // along the axis the range extends furthest in.  Every group of 8, 64 or 4096 consecutive primitives is
-    // then a box-shaped cell of the split.  (RT355_GENERAL_ORDER=morton keeps the plain Morton order.)
+    // Order: the order of the 8-ary tree of walk_ray.  A node's run (8 S consecutive primitives, S a power of 8; the
+    // last node of a level may hold fewer) is cut by position at 4 S, its halves at 2 S and 6 S, its quarters at S, 3 S,
+    // 5 S and 7 S -- each piece along the axis its centres extend furthest in, the lower coordinates first.  Every
+    // group of 8, 64, 512, 4096 ... consecutive primitives is then a box-shaped cell: the children of the tree's nodes,
+    // and the groups of the beam search's three levels.
+    // (RT355_GENERAL_ORDER=morton keeps the plain Morton order.)
+    int n_lvls = prims.empty() ? 0 : 1;
+    for (size_t span = 8; span < prims.size(); span *= 8) n_lvls++;
     std::vector<BoundSphere> sorted(prims.size());
     if (getenv("RT355_GENERAL_ORDER") && !strcmp(getenv("RT355_GENERAL_ORDER"), "morton")) {
         std::vector<std::pair<uint64_t, uint32_t>> order(prims.size());
@@ -3797,24 +3829,31 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
         for (size_t i = 0; i < prims.size(); i++) sorted[i] = prims[order[i].second];
     } else {
         sorted = prims;
-        std::vector<std::pair<size_t, size_t>> todo{{0, sorted.size()}};
+        struct Run { size_t b, e; int L; };
+        std::vector<Run> todo;
+        if (n_lvls) todo.push_back({0, sorted.size(), 0});
         while (!todo.empty()) {
-            const size_t b = todo.back().first, e = todo.back().second;
+            const Run r = todo.back();
             todo.pop_back();
-            const size_t len = e - b;
-            if (len <= 8) continue;
-            const size_t g = len > 4096 ? 4096 : (len > 64 ? 64 : 8);
-            size_t mid = b + std::max<size_t>(1, (len / 2 + g / 2) / g) * g; // b is a multiple of g by construction
-            if (mid >= e) mid = b + (len - 1) / g * g;
-            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-            for (size_t i = b; i < e; i++)
-                for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], sorted[i].c[a]); mx[a] = std::max(mx[a], sorted[i].c[a]); }
-            int axis = 0;
-            for (int a = 1; a < 3; a++) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
-            std::nth_element(sorted.begin() + b, sorted.begin() + mid, sorted.begin() + e,
-                             [axis](const BoundSphere &p, const BoundSphere &q) { return p.c[axis] < q.c[axis]; });
-            todo.push_back({b, mid});
-            todo.push_back({mid, e});
+            const size_t S = size_t(1) << (3 * (n_lvls - 1 - r.L)); // a child's run
+            // three rounds of cuts: the run, its halves, its quarters (pieces past the run's end are empty, and a piece
+            // that ends before its middle is not cut)
+            for (int round = 0; round < 3; round++) {
+                const size_t piece = (8 * S) >> round; // length of a whole piece
+                for (size_t pb = r.b; pb < r.e; pb += piece) {
+                    const size_t pe = std::min(r.e, pb + piece), mid = pb + piece / 2;
+                    if (mid >= pe) continue;
+                    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                    for (size_t i = pb; i < pe; i++)
+                        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], sorted[i].c[a]); mx[a] = std::max(mx[a], sorted[i].c[a]); }
+                    int axis = 0;
+                    for (int a = 1; a < 3; a++) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+                    std::nth_element(sorted.begin() + pb, sorted.begin() + mid, sorted.begin() + pe,
+                                     [axis](const BoundSphere &p, const BoundSphere &q) { return p.c[axis] < q.c[axis]; });
+                }
+            }
+            if (S > 1)
+                for (size_t cb = r.b; cb < r.e; cb += S) todo.push_back({cb, std::min(r.e, cb + S), r.L + 1});
         }
     }
     const size_t n_chunks = (sorted.size() + 63) / 64, n_supers = (n_chunks + 63) / 64;
@@ -3839,8 +3878,6 @@ static int build_general_table(rt355_scene *sc, const std::vector<DObject> &objs
     for (size_t k = 0; k < n_supers; k++) super_rows[k] = to_row(enclose(&chunks[k * 64], std::min<size_t>(64, n_chunks - k * 64)));
     // the 8-ary tree of walk_ray: every level's boxes straight from the primitives of the run, moved out by
     // 2^-18 of (the largest coordinate sum of the box + 1), then put on the byte grid of their group
-    int n_lvls = sorted.empty() ? 0 : 1;
-    for (size_t span = 8; span < sorted.size(); span *= 8) n_lvls++;
     const size_t last_at = n_lvls ? ((size_t(8) << (3 * (n_lvls - 1))) - 8) / 7 : 0; // nodes above the last level
     const size_t n_groups_q = std::max<size_t>(1, last_at / 8 + (sorted.size() + 7) / 8);
     std::vector<uint32_t> nodes(n_groups_q * 16, 0u);
