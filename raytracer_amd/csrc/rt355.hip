@@ -236,10 +236,14 @@ struct Work { // per-ray buffers, all indexed by rid (SoA)
     double *ktotal;       // reflection_ktotal after the deepest level so far
     uint32_t *deepest;    // deepest level the chain of this sub-sample reached
     double *ray_d;        // [6] the ray of the level being traced: pe.xyz, npe.xyz
-    // The rays of a level after the first are numbered densely, in the order of the level's compacted list: dense
-    // index d < lvl_live[level] stands for ray dense_rid[d] of the frame, and every per-ray array of the level (hit
-    // record, fp32 records, candidates, bins) is indexed by d, so that the level's kernels run over its live chains
-    // only; the arrays that outlive a level (ray_d, ktotal, deepest, lvl_clr, lvl_ks) stay indexed by the frame's rid.
+    // The rays of a level after the first are numbered densely: dense index d < lvl_live[level] stands for ray
+    // dense_rid[d] of the frame, and every per-ray array of the level (hit record, fp32 records of the shadow rays,
+    // their candidates, bins) is indexed by d, so that the level's kernels run over its live chains only; the arrays
+    // that outlive a level (ray_d, ktotal, deepest, lvl_clr, lvl_ks) stay indexed by the frame's rid.  The mirror rays'
+    // own candidates are kept under their place in the level's compacted list; k_resolve_primary then numbers every
+    // LEVEL_GROUP consecutive places (a workgroup's) anew, the rays that hit something from the first place up and the others from the last place
+    // down (mirror rays that miss lie scattered among those that hit, and the shading kernel, which has nothing to do
+    // for them, would run with the lanes of every wave half empty: now at most one wave of a group is mixed).
     uint32_t *lvl_live;   // [4] live chains of each level
     uint32_t *dense_rid;  // [n] the frame's rid of dense index d of the level being traced
     // the gather shaders on searched scenes (allocated when such a frame is rendered), see k_gather_init
@@ -3147,72 +3151,102 @@ __global__ __launch_bounds__(256) void k_gather_finish(SceneView s, ShaderView s
 // LEVELS: the frame is rendered level by level (mirror rays on a searched scene); compiled apart so that frames
 // without levels run the kernel they always ran.  ENV: the scene holds an Environment or a quadric (their tests
 // are compiled out otherwise).
+#ifndef LEVEL_GROUP
+#define LEVEL_GROUP 256 // threads of a workgroup that resolves a level after the first: the places it numbers anew (512, 1024: the kernel and the shading after it both slower)
+#endif
 template <bool LEVELS, bool ENV>
-__global__ __launch_bounds__(256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f_in, Work w,
+__global__ __launch_bounds__(LEVELS ? LEVEL_GROUP : 256) void k_resolve_primary(SceneView s, ShaderView sh, DCamera cam, Frame f_in, Work w,
                                                          int brute, Group first,
                                                          unsigned char *__restrict__ pixmap) {
     Frame f = f_in;
     if (!LEVELS) f.level = -1;
-    uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // (a level after the first: the dense index, see Work::dense_rid)
-    uint32_t out_rid = rid;                               // ... and the frame's rid, under which the level's colour is kept
+    const uint32_t rid = blockIdx.x * blockDim.x + threadIdx.x; // (a level after the first: the place in the level's list of rays)
+    uint32_t slot = rid;    // where the ray's records go: rid, or on a level after the first its dense index (see Work::dense_rid)
+    uint32_t out_rid = rid; // ... and the frame's rid, under which the level's colour is kept
     uint32_t n_eval = 0, n_over = 0, n_hit = 0;
     bool got_hit = false;
     d3 ph = D3(0, 0, 0), nh = D3(0, 0, 0);
-    do {
-    if (rid >= f.n_rays) break;
+    const bool later = LEVELS && f.level > 0; // uniform
     int x = 0, y = 0;
     Ray e;
-    if (LEVELS && f.level > 0) { // the mirror rays of level f.level (k_reflect_rays left them in ray_d), in the order of their compacted list
-        if (rid >= w.lvl_live[f.level]) break;
-        out_rid = w.active_rid[rid];
-        w.dense_rid[rid] = out_rid;
+    // what is kept of a ray whose closest hit is known: the hit record under `slot`, or the miss
+    auto record = [&](const Closest &c) {
+        if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
+            w.rec_obj[slot] = -1;
+            if (sh.n_lights == 0) store_pixel(pixmap, f, w, out_rid, x, y, 0u);
+            return;
+        }
+        n_hit = f.level > 0 ? 0 : 1; // rt355_stats.primary_hits counts camera rays
+        const bool environment = ENV && s.objects[s.prim_obj[c.prim_best]].type == RT_OBJ_ENVIRONMENT;
+        if (sh.n_lights == 0 && f.level < 0 && !environment) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
+            w.rec_obj[slot] = s.prim_obj[c.prim_best];
+            store_pixel(pixmap, f, w, out_rid, x, y, 0u);
+            return;
+        }
+        const HitRec h = primary_record<ENV>(s, sh, e, c);
+        if (sh.n_lights == 0) store_pixel(pixmap, f, w, out_rid, x, y, h.emissive ? h.cm0 : 0u); // (levels: the mirror ray still needs ph and nh)
+        ph = h.ph; nh = h.nh;
+        got_hit = !h.emissive; // an Environment is not lit: no shadow rays (shader.h:70-72)
         const size_t n = f.n_rays;
-        e.pe = D3(w.ray_d[0 * n + out_rid], w.ray_d[1 * n + out_rid], w.ray_d[2 * n + out_rid]);
-        e.npe = D3(w.ray_d[3 * n + out_rid], w.ray_d[4 * n + out_rid], w.ray_d[5 * n + out_rid]);
-    } else {
+        w.rec_obj[slot] = h.obj;
+        w.rec_d[0 * n + slot] = ph.x; w.rec_d[1 * n + slot] = ph.y; w.rec_d[2 * n + slot] = ph.z;
+        w.rec_d[3 * n + slot] = nh.x; w.rec_d[4 * n + slot] = nh.y; w.rec_d[5 * n + slot] = nh.z;
+        w.rec_d[6 * n + slot] = h.reh.x; w.rec_d[7 * n + slot] = h.reh.y; w.rec_d[8 * n + slot] = h.reh.z;
+        if (!h.no_border) w.rec_d[9 * n + slot] = h.border_w;
+        const bool far = !(fabs(ph.x) + fabs(ph.y) + fabs(ph.z) < s.far_origin); // see FAR_SCALE
+        if (far && !h.emissive && sh.n_lights) { // (rare: two atomics per such hit)
+            atomicAdd(&w.counters[15], 1ull);
+            w.far_list[atomicAdd(w.far_n, 1u)] = slot;
+        }
+        w.rec_cm0[slot] = h.cm0 | (h.no_border ? (1u << 24) : 0u) | (h.emissive ? (1u << 25) : 0u) | (far ? (1u << 26) : 0u);
+        w.rec_cm1[slot] = h.cm1;
+    };
+    if (!later) { // camera rays
+        do {
+        if (rid >= f.n_rays) break;
         rid_to_xy(rid, f.tiles_x, &x, &y);
         if (!(x < f.grid_w && y < f.grid_h)) {
             w.rec_obj[rid] = -2;
             break;
         }
         e = grid_ray(cam, f, x, y);
-    }
-    Closest c;
-    if (LEVELS && f.level > 0) // mirror rays: their candidates come from walk_ray
-        closest_hit<false, ENV, true>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
-    else
+        Closest c;
         closest_hit<false, ENV>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
-    if (c.prim_best < 0) { // main.cpp:83: no hit -> Color(0,0,0)
-        w.rec_obj[rid] = -1;
-        if (sh.n_lights == 0) store_pixel(pixmap, f, w, out_rid, x, y, 0u);
-        break;
+        record(c);
+        } while (0);
+    } else { // the mirror rays of level f.level (k_reflect_rays left them in ray_d), in the order of their compacted list
+        const bool active = rid < f.n_rays && rid < w.lvl_live[f.level];
+        Closest c;
+        c.init();
+        if (active) {
+            out_rid = w.active_rid[rid];
+            const size_t n = f.n_rays;
+            e.pe = D3(w.ray_d[0 * n + out_rid], w.ray_d[1 * n + out_rid], w.ray_d[2 * n + out_rid]);
+            e.npe = D3(w.ray_d[3 * n + out_rid], w.ray_d[4 * n + out_rid], w.ray_d[5 * n + out_rid]);
+            // (their candidates come from walk_ray)
+            closest_hit<false, ENV, true>(s, e, brute != 0, rid, f.n_rays, w.cand, w.cand_cnt, w.spill, c, n_eval, n_over);
+        }
+        // the level's dense numbering: within the workgroup's places, hits from the front and misses from the back
+        __shared__ uint32_t wave_hits[LEVEL_GROUP / 64], wave_rays[LEVEL_GROUP / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned long long hits = __ballot(active && c.prim_best >= 0), rays = __ballot(active);
+        if (lane == 0) { wave_hits[wave] = (uint32_t)__popcll(hits); wave_rays[wave] = (uint32_t)__popcll(rays); }
+        __syncthreads();
+        uint32_t hits_before = 0u, misses_before = 0u, in_group = 0u;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) { // uniform
+            if (k < wave) { hits_before += wave_hits[k]; misses_before += wave_rays[k] - wave_hits[k]; }
+            in_group += wave_rays[k];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (active) {
+            const uint32_t group_first = blockIdx.x * blockDim.x;
+            slot = c.prim_best >= 0 ? group_first + hits_before + (uint32_t)__popcll(hits & below)
+                                    : group_first + in_group - 1u - (misses_before + (uint32_t)__popcll(rays & ~hits & below));
+            w.dense_rid[slot] = out_rid;
+            record(c);
+        }
     }
-    n_hit = f.level > 0 ? 0 : 1; // rt355_stats.primary_hits counts camera rays
-    const bool environment = ENV && s.objects[s.prim_obj[c.prim_best]].type == RT_OBJ_ENVIRONMENT;
-    if (sh.n_lights == 0 && f.level < 0 && !environment) { // Shader::shading with no lights returns clr_sum = (0,0,0), shader.h:49,95
-        w.rec_obj[rid] = s.prim_obj[c.prim_best];
-        store_pixel(pixmap, f, w, out_rid, x, y, 0u);
-        break;
-    }
-    const HitRec h = primary_record<ENV>(s, sh, e, c);
-    if (sh.n_lights == 0) store_pixel(pixmap, f, w, out_rid, x, y, h.emissive ? h.cm0 : 0u); // (levels: the mirror ray still needs ph and nh)
-    ph = h.ph; nh = h.nh;
-    got_hit = !h.emissive; // an Environment is not lit: no shadow rays (shader.h:70-72)
-    const size_t n = f.n_rays;
-    w.rec_obj[rid] = h.obj;
-    w.rec_d[0 * n + rid] = ph.x; w.rec_d[1 * n + rid] = ph.y; w.rec_d[2 * n + rid] = ph.z;
-    w.rec_d[3 * n + rid] = nh.x; w.rec_d[4 * n + rid] = nh.y; w.rec_d[5 * n + rid] = nh.z;
-    w.rec_d[6 * n + rid] = h.reh.x; w.rec_d[7 * n + rid] = h.reh.y; w.rec_d[8 * n + rid] = h.reh.z;
-    if (!h.no_border) w.rec_d[9 * n + rid] = h.border_w;
-    const bool far = !(fabs(ph.x) + fabs(ph.y) + fabs(ph.z) < s.far_origin); // see FAR_SCALE
-    if (far && !h.emissive && sh.n_lights) { // (rare: two atomics per such hit)
-        atomicAdd(&w.counters[15], 1ull);
-        w.far_list[atomicAdd(w.far_n, 1u)] = rid;
-    }
-    w.rec_cm0[rid] = h.cm0 | (h.no_border ? (1u << 24) : 0u) | (h.emissive ? (1u << 25) : 0u) | (far ? (1u << 26) : 0u);
-    w.rec_cm1[rid] = h.cm1;
-    } while (0);
-    const uint32_t n_shadow = emit_shadow_rays(sh, first, w, rid, rid < f.n_rays, got_hit && sh.n_lights, ph, nh, f.soft != 0);
+    const uint32_t n_shadow = emit_shadow_rays(sh, first, w, slot, rid < f.n_rays, got_hit && sh.n_lights, ph, nh, f.soft != 0);
     wave_count(w.counters, 4, n_hit);
     wave_count(w.counters, 0, n_shadow);
     wave_count(w.counters, 1, n_eval);
@@ -4783,7 +4817,9 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         {
             const int brute_l = (L == 0 && !bundles[0].kind) ? 1 : 0;
             const bool env = sc->view.n_envs + sc->view.n_quadrics > 0;
-#define LAUNCH_RESOLVE(LV, E) hipLaunchKernelGGL((k_resolve_primary<LV, E>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, fl, w, brute_l, cur, pix)
+            // (a level after the first: larger workgroups, see Work::dense_rid)
+            const unsigned group = (levels && L > 0) ? LEVEL_GROUP : 256u;
+#define LAUNCH_RESOLVE(LV, E) hipLaunchKernelGGL((k_resolve_primary<LV, E>), dim3((f.n_rays + group - 1) / group), dim3(group), 0, st, sc->view, sh, dc, fl, w, brute_l, cur, pix)
             if (levels) { if (env) LAUNCH_RESOLVE(true, true); else LAUNCH_RESOLVE(true, false); }
             else { if (env) LAUNCH_RESOLVE(false, true); else LAUNCH_RESOLVE(false, false); }
 #undef LAUNCH_RESOLVE
