@@ -2186,9 +2186,11 @@ __device__ __forceinline__ SoftArgs soft_args(const Frame &f, int gx, int gy) {
 // lights[0].position + n0 * sx * m + n1 * sy * n of lights[0]'s area whichever light is being shaded (:441-443), the
 // facing test takes the vector to that point as it is (:445-446), L stays the distance to light k's position (:462).
 // SKIP: leave out the highlight and the shadow mix where they change nothing (see calc_specular, shadow_mix).
+// light_colour: what light k gives the hit, shadow included (shader.h:75-92); shade_light: that, taken into the
+// running mean over the lights (shader.h:93).
 template <bool SOFT = false, bool SKIP = false, class Occluder>
-__device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, const HitRec &h, uint32_t sum,
-                                                Occluder occluder, uint32_t &n_shadow, double soft_m = 0, double soft_n = 0) {
+__device__ __forceinline__ uint32_t light_colour(const ShaderView &sh, int k, const HitRec &h,
+                                                 Occluder occluder, uint32_t &n_shadow, double soft_m = 0, double soft_n = 0) {
     const DLight &L = sh.lights[k];
     // nhl of shader.h:75-82, and with it |ph - position|: CalcShadow's L = |position - ph| (shader.h:412) is the same
     // double (the components are negated exactly, so the squares and their sum are the same), one square root saved
@@ -2225,8 +2227,12 @@ __device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, con
         shd = (t_min > 0 && t_min < Ld) ? t_min / Ld : 1.0;
         n_shadow += 1;
     }
-    clr = shadow_mix<SKIP>(sh, L, clr, nhl, shd);
-    return light_mean(sum, clr, k);
+    return shadow_mix<SKIP>(sh, L, clr, nhl, shd);
+}
+template <bool SOFT = false, bool SKIP = false, class Occluder>
+__device__ __forceinline__ uint32_t shade_light(const ShaderView &sh, int k, const HitRec &h, uint32_t sum,
+                                                Occluder occluder, uint32_t &n_shadow, double soft_m = 0, double soft_n = 0) {
+    return light_mean(sum, light_colour<SOFT, SKIP>(sh, k, h, occluder, n_shadow, soft_m, soft_n), k);
 }
 
 // The whole pixel in one thread, the reference's way (every primitive tested in fp64 for the camera ray and
@@ -2440,10 +2446,10 @@ __global__ __launch_bounds__(256) void k_list_children(SceneView s, Frame f, Wor
 // as before.  The other rays keep the colour they have.
 // LG > 1 (CHILDREN only): LG neighbouring lanes stand for one listed ray.  All of them run the ray's recursion, in
 // step and on the same values; where a node is shaded, the walks of its shadow rays -- most of what a node costs, one
-// walk per light that the hit faces -- are dealt to the lanes of the group (light k to lane k mod LG, each lane with
-// workspace slot `lane in group` for its candidates) and the distances handed round with shuffles, so that a node
-// takes the time of two walks instead of one plus one per light.  Lane 0 of a group counts the statistics that are the
-// ray's, every lane those of the shadow walks it made.
+// walk per light that the hit faces -- and the lights' colours are dealt to the lanes of the group (light k to lane
+// k mod LG, each lane with workspace slot `lane in group` for its candidates) and the colours handed round with
+// shuffles, so that a node takes the time of two walks and two lights instead of one walk plus one walk and one light
+// per light.  Lane 0 of a group counts the statistics that are the ray's, every lane those of the shadow rays it cast.
 template <bool SOFT, bool WALK, bool CHILDREN = false, int LG = 1>
 __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderView sh, DCamera cam, Frame f, Work w_all,
                                                         GeneralTable table, unsigned char *__restrict__ pixmap) {
@@ -2515,28 +2521,20 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
                 ph = h.ph; nh = h.nh; oi = h.obj;
                 if (h.emissive) own = h.cm0;
                 if (LG > 1) {
-                    // LG lights at a time: this lane walks for light k0 + sub (the facing test and the ray as shade_light
-                    // makes them), then the group shades the LG lights in order, each distance read from its lane
+                    // LG lights at a time: this lane makes light k0 + sub's colour, its shadow ray's walk included, then
+                    // the group takes the LG colours into the running mean in the lights' order, each read from its lane
                     const uint32_t lane = threadIdx.x & 63u, group0 = lane - sub;
                     for (int k0 = 0; !h.emissive && k0 < sh.n_lights; k0 += LG) {
-                        double my_t = RT_FLT_MAX;
+                        uint32_t my_clr = 0u;
                         const int km = k0 + (int)sub;
-                        if (km < sh.n_lights) {
-                            const DLight &L = sh.lights[km];
-                            const d3 nhl = light_nhl(L, h.ph);
-                            if (!(dot(h.nh, vmul(nhl, -1)) <= 0)) { // shader.h:396
-                                Ray sr;
-                                if (L.type == 0) { sr.pe = h.ph; sr.npe = ld3(L.shadow_dir); }
-                                else sr = mkview(h.ph, vmul(nhl, -1));
+                        if (km < sh.n_lights)
+                            my_clr = light_colour<SOFT, true>(sh, km, h, [&](const Ray &sr) {
                                 Closest o;
                                 closest(sr, o);
-                                my_t = o.t_best;
-                            }
-                        }
-                        for (int j = 0; j < LG && k0 + j < sh.n_lights; j++) {
-                            const double t_j = __shfl(my_t, (int)(group0 + (uint32_t)j), 64);
-                            own = shade_light<SOFT, true>(sh, k0 + j, h, own, [&](const Ray &) { return t_j; }, n_shadow);
-                        }
+                                return o.t_best;
+                            }, n_shadow);
+                        for (int j = 0; j < LG && k0 + j < sh.n_lights; j++)
+                            own = light_mean(own, (uint32_t)__shfl((int)my_clr, (int)(group0 + (uint32_t)j), 64), k0 + j);
                     }
                 } else {
                     for (int k = 0; !h.emissive && k < sh.n_lights; k++)
@@ -2634,7 +2632,7 @@ __global__ __launch_bounds__(256, 3) void k_render_refract(SceneView s, ShaderVi
     } while (0);
     if (CHILDREN) { if (valid && changed && sub == 0) w.rec_sum[rid] = pixel; } // (k_average writes the pixmap)
     else direct_store(pixmap, f, w, x, y, valid, pixel);
-    if (LG > 1 && sub != 0) { n_hit = 0; n_shadow = 0; n_secondary = 0; n_deep = 0; } // (the ray's own: counted by lane 0 of its group)
+    if (LG > 1 && sub != 0) { n_hit = 0; n_secondary = 0; n_deep = 0; } // (the ray's own: counted by lane 0 of its group)
     block_count<7>(w.counters, {4, 0, 1, 2, 6, 14, 5}, {n_hit, n_shadow, n_eval, n_over, n_secondary, n_deep, WALK ? n_pairs : 0u});
 }
 
