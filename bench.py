@@ -133,7 +133,7 @@ def sweep_of(name: str, w: int, h: int):
 
 
 # the partition a workload is meant for when --shard is left at its default
-DEFAULT_SHARD = {"mesh1m_8k_tiles": "tiles", "mesh1m_8k_slabs": "slabs", "spheres10k_tiles": "tiles"}
+DEFAULT_SHARD = {"mesh1m_8k_tiles": "balanced", "mesh1m_8k_slabs": "slabs", "spheres10k_tiles": "balanced"}
 
 
 def gather_of(name: str):
@@ -323,14 +323,16 @@ def measure(name, args, ctx, light=False):
     import torch
     from raytracer_amd import binding as B
     from raytracer_amd.api import HostPixmap, Renderer
-    from raytracer_amd.sharding import SharedPixmap, frames_for_rank, gather_frame, host_barrier, rows_of, TILE_ROWS
+    from raytracer_amd.sharding import SharedPixmap, SlabBalancer, frames_for_rank, gather_frame, host_barrier, rows_of, TILE_ROWS
     dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
 
     scene, shader, cam, w, h = build_workload(name)
     shading, dirs = gather_of(name)
     cams = sweep_of(name, w, h)
     shard = args.shard or DEFAULT_SHARD.get(name, "frames")
-    split = world > 1 and shard in ("slabs", "tiles") and cams is None  # one frame between the ranks
+    if shard == "balanced" and args.gather != "host":
+        shard = "tiles"  # (the shares' times travel through the shared pixmap's page)
+    split = world > 1 and shard in ("slabs", "tiles", "balanced") and cams is None  # one frame between the ranks
     r = Renderer(scene)
     if dirs is not None:
         r.set_directions(dirs)
@@ -342,8 +344,15 @@ def measure(name, args, ctx, light=False):
 
     shared = None
     if split:
+        balancer = None
         if shard == "tiles":
             o_part = B.opts(w, h, mode=mode, shading=shading, tile_rows=TILE_ROWS, tile_count=world, tile_phase=rank)
+        elif shard == "balanced":
+            # contiguous slabs whose cuts follow the times the shares took in the frame before (every rank keeps the
+            # same balancer and feeds it the same numbers); the cuts move in the warm-up steps and stay for the timed ones
+            balancer = SlabBalancer(h, world)
+            b, e = balancer.slabs()[rank]
+            o_part = B.opts(w, h, row_begin=b, row_end=e, mode=mode, shading=shading)
         else:
             b, e = rows_of(h, world, rank, "slabs")[0]
             o_part = B.opts(w, h, row_begin=b, row_end=e, mode=mode, shading=shading)
@@ -356,14 +365,24 @@ def measure(name, args, ctx, light=False):
             rt355_render, st_part = lib().rt355_render, CStats()
             part_args = (r.handle, C.byref(cam), C.byref(shader.c), C.byref(o_part), shared.array.ctypes.data, C.byref(st_part))
 
+        balance = {"on": balancer is not None, "best": None, "best_cuts": None}
+
         def step():
             if shared is not None:
                 # this rank's rows straight into the one pixmap all ranks share, over this GPU's own link to the host;
                 # the frame is complete when every rank's rows have arrived
+                t_call = time.perf_counter()
                 rc = rt355_render(*part_args)
                 if rc:
                     _check(rc, "rt355_render")
-                shared.barrier()  # (arrival counters in the shared mapping itself: microseconds, no collective)
+                if balance["on"]:
+                    times = shared.barrier_with_times(time.perf_counter() - t_call)
+                    if balance["best"] is None or max(times) < balance["best"]:
+                        balance["best"], balance["best_cuts"] = max(times), list(balancer.cuts)
+                    balancer.update(times)
+                    o_part.row_begin, o_part.row_end = balancer.slabs()[rank]
+                else:
+                    shared.barrier()  # (arrival counters in the shared mapping itself: microseconds, no collective)
                 st = st_part.as_dict()
                 return count_rays(st), st
             # this rank's rows into its framebuffer in HBM, the final frame gathered on rank 0 (RCCL), read back there
@@ -426,6 +445,11 @@ def measure(name, args, ctx, light=False):
     import gc
     for _ in range(args.warmup):
         step()
+    if split and shared is not None and balancer is not None and balance["best_cuts"] is not None:
+        # the timed steps run on the best cuts the warm-up found (the same on every rank)
+        balance["on"] = False
+        balancer.cuts = balance["best_cuts"]
+        o_part.row_begin, o_part.row_end = balancer.slabs()[rank]
     barrier()
     gc.disable()  # no collector pause inside the timed steps
     t0 = time.perf_counter()
@@ -675,6 +699,9 @@ def measure_inproc(name, args, devices):
         r.set_directions(dirs)
     if args.gather == "xgmi":
         r.set_option("gather", 1)
+    shard = args.shard or DEFAULT_SHARD.get(name, "frames")
+    if cams is None and shard == "balanced" and n > 1:
+        r.set_option("balance", 1)  # contiguous slabs, cut by what the devices' shares took in the calls before
     o = B.opts(w, h, mode=B.MODE_PACKET if args.mode == "packet" else B.MODE_ALLPAIRS, shading=shading)
     pix = [HostPixmap(w, h) for _ in (cams or [None])]
     arrays = [p.array for p in pix]
@@ -707,7 +734,8 @@ def measure_inproc(name, args, devices):
             "ms_per_step": round(dt * 1e3 / args.steps, 4), "scaling": "weak" if weak else "strong", "gathered_frame": "ok",
             "timed": "one process, rt355_scene_create_multi over %d devices: %s" % (n, "rt355_render_sweep" if cams is not None else "rt355_render"),
             "config": {"workload": name, "width": w, "height": h, "primitives": scene.n_primitives, "lights": len(shader.lights), "alias": 0,
-                       "shard": "frames" if cams is not None else "tiles", "frames_per_step": len(cams) if cams is not None else 1, "search": args.mode,
+                       "shard": "frames" if cams is not None else ("balanced" if shard == "balanced" and n > 1 else "tiles"),
+                       "frames_per_step": len(cams) if cams is not None else 1, "search": args.mode,
                        "rays_per_frame": {"primary": sts[-1]["primary_rays"], "shadow": sts[-1]["shadow_rays"],
                                           "gather": sts[-1]["gather_rays"], "mirror": sts[-1]["secondary_rays"]}}}
 
@@ -824,6 +852,26 @@ def compact_line(head, others, scaling, world, steps, warmup):
     return out
 
 
+# The line goes to the descriptor that was standard output when the process started; descriptor 1 itself points at
+# standard error from then on, so that nothing a library prints (gloo reports its connections on standard output,
+# in lines that begin with a bracket) can stand before or behind the line.
+_LINE_FD = None
+
+
+def own_stdout():
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def say_line(text: str):
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.write(_LINE_FD if _LINE_FD is not None else 1, (text + "\n").encode())
+
+
 def emit(line: dict, detail: dict, detail_name: str = "bench_detail.json"):
     """bench_detail.json first, then the line: the last thing the run writes, on stdout, with stderr flushed before it."""
     text = json.dumps(line, separators=(",", ":"))
@@ -837,8 +885,7 @@ def emit(line: dict, detail: dict, detail_name: str = "bench_detail.json"):
                     json.dump(detail, f, indent=1)
             except OSError:
                 pass
-    sys.stderr.flush()
-    print(text, flush=True)
+    say_line(text)
     return text
 
 
@@ -885,7 +932,7 @@ def check_launch(args) -> int:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"launch": "ok", "n_gpus": world, "rank_sum": float(seen.item())}), flush=True)
+        say_line(json.dumps({"launch": "ok", "n_gpus": world, "rank_sum": float(seen.item())}))
     return 0
 
 
@@ -895,7 +942,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=HEADLINE)
-    ap.add_argument("--shard", choices=["frames", "slabs", "tiles"], default=None,
+    ap.add_argument("--shard", choices=["frames", "slabs", "tiles", "balanced"], default=None,
                     help="N > 1: whole frames per rank (default), or one frame in row slabs / interleaved 32-row tiles")
     ap.add_argument("--gather", choices=["host", "xgmi"], default="host",
                     help="--shard slabs|tiles: where the frame comes together -- host: every rank writes its rows into one "
@@ -919,10 +966,11 @@ def main():
                     help="start the ranks, meet over gloo, print {\"launch\": \"ok\", ...} and stop: no GPU is touched")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inproc:
+        sys.exit(spawn_ranks(args.gpus))  # (before anything in this process touches the GPU; the ranks inherit standard output)
+    own_stdout()
     if args.inproc:
         sys.exit(run_inproc(args))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))  # (before anything in this process touches the GPU)
     if args.check_launch:
         sys.exit(check_launch(args))
 

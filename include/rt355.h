@@ -276,7 +276,10 @@ void rt355_scene_destroy(rt355_scene *scene);
  *                       where the pixmap is page-locked (rt355_host_alloc, rt355_host_register), each device's
  *                       staging memory and a host copy where it is not; opts->tile_count must be left at 0.
  *                       With the option "gather" set to 1 (rt355_scene_set_option) the shares are rendered into
- *                       HBM, copied to devices[0] over the GPUs' own links and read back from there in one transfer;
+ *                       HBM, copied to devices[0] over the GPUs' own links and read back from there in one transfer.
+ *                       With the option "balance" set to 1 the slab is dealt in n contiguous runs of rows instead, whose
+ *                       cuts follow the times the devices' shares took in the calls before (a renderer of successive
+ *                       frames of one scene; the first call cuts the slab evenly);
  *   rt355_render_sweep  deals whole frames, frame f to device f mod n;
  *   rt355_scene_set_directions, rt355_scene_set_option reach every device; statistics are summed over the devices
  *                       (ms_device: the longest); the kernel-time queries and rt355_probe_intersect answer for
@@ -404,6 +407,8 @@ double rt355_strata(uint32_t seed, int32_t x, int32_t y, int32_t which);
  *   "walk_blocks"     workgroups of the searched gather's walk (default 8192)
  *   "gather"          multi-device scenes only: 0 = every GPU writes its rows into the host pixmap (default), 1 = rows
  *                     gathered on the first device and read back from there
+ *   "balance"         multi-device scenes only: 0 = a frame is dealt in interleaved 32-row tiles (default), 1 = in
+ *                     contiguous slabs whose cuts are moved after every call by what each device's share took
  *   "tail_bottom_first", "tail_even", "copy_streams", "last_copied", "no_copy_prime", "debug_readback": measurement aids
  * RT355_ERR_ARG for a name that is not listed or a value out of range. */
 int rt355_scene_set_option(rt355_scene *scene, const char *name, int64_t value);

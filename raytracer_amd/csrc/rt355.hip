@@ -3697,11 +3697,58 @@ struct MultiWorker {
     int rc = RT355_OK;
     std::string err;
 };
+// Row cuts of contiguous slabs, one per device, moved from frame to frame so that the slabs take the same time.  A
+// slab's time is read as a part every share pays whatever its size (half the fastest share's time: launches, fills,
+// the searches' depth) plus the sum of a cost per run of `align` rows (the packets of the search are 16 pixels high);
+// after a frame the costs of a slab's runs are scaled so that they add up to what the slab took -- the profile keeps
+// what earlier cuts have shown of it, and sharpens where the cuts move -- and the new cuts divide the summed cost evenly.
+struct SlabBalance {
+    int y0 = 0, y1 = 0, n = 0, align = 16;
+    std::vector<double> cost; // per run of rows
+    std::vector<int> cuts;    // n + 1 rows, y0 first and y1 last
+    bool fits(int a, int b, int parts) const { return a == y0 && b == y1 && parts == n; }
+    void start(int a, int b, int parts) {
+        y0 = a; y1 = b; n = parts;
+        align = (b - a) >= parts * 16 ? 16 : 1;
+        cost.assign((size_t)((b - a + align - 1) / align), 1.0);
+        cut();
+    }
+    void cut() {
+        const int runs = (int)cost.size();
+        double total = 0;
+        for (double c : cost) total += c;
+        cuts.assign(1, y0);
+        int run = 0;
+        double done = 0; // the runs before `run` add up to `done`
+        for (int j = 1; j < n; j++) {
+            const double want = total * j / n;
+            while (run < runs - 1 && done + cost[run] <= want) { done += cost[run]; run++; }
+            const int at = run + (want - done > 0.5 * cost[run] ? 1 : 0); // the nearer end of the run the target falls in
+            const int lo = (cuts.back() - y0) / align + 1, hi = runs - (n - j);
+            cuts.push_back(y0 + std::max(lo, std::min(hi, at)) * align);
+        }
+        cuts.push_back(y1);
+    }
+    void update(const std::vector<double> &ms) {
+        double fastest = ms[0];
+        for (double t : ms) fastest = std::min(fastest, t);
+        for (int k = 0; k < n; k++) {
+            const int first = (cuts[k] - y0) / align, last = (cuts[k + 1] - y0 + align - 1) / align;
+            double have = 0;
+            for (int r = first; r < last; r++) have += cost[r];
+            const double scale = std::max(ms[k] - 0.5 * fastest, 1e-9) / std::max(have, 1e-30);
+            for (int r = first; r < last; r++) cost[r] *= scale;
+        }
+        cut();
+    }
+};
 struct MultiScene {
     std::vector<rt355_scene *> scenes;
     std::vector<int> devices;
     std::vector<std::unique_ptr<MultiWorker>> workers;
-    int gather = 0; // 0: every GPU writes its rows into the host pixmap; 1: rows gathered on the first GPU, one readback
+    int gather = 0;  // 0: every GPU writes its rows into the host pixmap; 1: rows gathered on the first GPU, one readback
+    int balance = 0; // 0: a frame is dealt in interleaved 32-row tiles; 1: in contiguous slabs whose cuts follow the times the shares took in the calls before
+    SlabBalance slabs;
 };
 extern "C" const char *rt355_last_error(void) { return g_err.c_str(); }
 extern "C" int rt355_abi_version(void) { return RT_ABI_VERSION; }
@@ -5554,16 +5601,24 @@ static int multi_render(rt355_scene *sc, const rt355_camera *cam, const rt355_sh
     { int rc0 = rows_of(opts, &rows); if (rc0) return rc0; }
     std::vector<rt355_stats> st((size_t)n);
     for (auto &s : st) memset(&s, 0, sizeof s);
+    // (slabs need a row each; a frame of fewer rows than devices goes in tiles, of which some devices get none)
+    const bool in_slabs = m.balance != 0 && n > 1 && rows.y1 - rows.y0 >= n;
+    if (in_slabs && !m.slabs.fits(rows.y0, rows.y1, n)) m.slabs.start(rows.y0, rows.y1, n);
+    std::vector<double> share_ms((size_t)n, 0.0);
     auto share_of = [&](int i) {
         rt355_opts o = *opts;
-        o.tile_rows = MULTI_TILE_ROWS; o.tile_count = n; o.tile_phase = i;
+        if (in_slabs) { o.row_begin = m.slabs.cuts[i]; o.row_end = m.slabs.cuts[i + 1]; }
+        else { o.tile_rows = MULTI_TILE_ROWS; o.tile_count = n; o.tile_phase = i; }
         return o;
     };
     int rc;
     if (m.gather == 0 || n == 1) {
         rc = multi_run(m, [&](int i) {
             const rt355_opts o = share_of(i);
-            return rt355_render(m.scenes[i], cam, shader, n == 1 ? opts : &o, pixmap, &st[i]);
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc1 = rt355_render(m.scenes[i], cam, shader, n == 1 ? opts : &o, pixmap, &st[i]);
+            share_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return rc1;
         });
     } else {
         const size_t row_bytes = (size_t)opts->width * 3, bytes = row_bytes * (size_t)opts->height;
@@ -5573,8 +5628,11 @@ static int multi_render(rt355_scene *sc, const rt355_camera *cam, const rt355_sh
             int rc1 = ensure_fb(r, bytes);
             if (rc1) return rc1;
             const rt355_opts o = share_of(i);
+            const auto t0 = std::chrono::steady_clock::now();
             if ((rc1 = render_enqueue(r, cam, shader, &o, r->fb, nullptr, &st[i], false))) return rc1;
-            return rt355_scene_sync(r);
+            rc1 = rt355_scene_sync(r);
+            share_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return rc1;
         });
         if (rc == RT355_OK)
             rc = multi_run(m, [&](int i) { // ... its rows to the first GPU over the link between the two
@@ -5585,7 +5643,12 @@ static int multi_render(rt355_scene *sc, const rt355_camera *cam, const rt355_sh
                     const hipError_t e = hipDeviceEnablePeerAccess(r0->device, 0);
                     if (e != hipSuccess) (void)hipGetLastError();
                 }
-                for (int k = i; k * MULTI_TILE_ROWS < rows.y1 - rows.y0; k += n) {
+                if (in_slabs) {
+                    const int ta = m.slabs.cuts[i], tb = m.slabs.cuts[i + 1];
+                    HIP_TRY(hipMemcpyPeerAsync(r0->fb + ta * row_bytes, r0->device, r->fb + ta * row_bytes, r->device,
+                                               (size_t)(tb - ta) * row_bytes, nullptr));
+                }
+                for (int k = i; !in_slabs && k * MULTI_TILE_ROWS < rows.y1 - rows.y0; k += n) {
                     const int ta = rows.y0 + k * MULTI_TILE_ROWS, tb = std::min(rows.y1, ta + MULTI_TILE_ROWS);
                     HIP_TRY(hipMemcpyPeerAsync(r0->fb + ta * row_bytes, r0->device, r->fb + ta * row_bytes, r->device,
                                                (size_t)(tb - ta) * row_bytes, nullptr));
@@ -5603,6 +5666,7 @@ static int multi_render(rt355_scene *sc, const rt355_camera *cam, const rt355_sh
             });
     }
     if (rc == RT355_OK) multi_sum(st, stats);
+    if (rc == RT355_OK && in_slabs) m.slabs.update(share_ms); // the next call's cuts
     return rc;
 }
 
@@ -5634,6 +5698,12 @@ extern "C" int rt355_scene_set_option(rt355_scene *sc, const char *name, int64_t
         if (!strcmp(name, "gather")) {
             if (value != 0 && value != 1) return fail(RT355_ERR_ARG, "option gather: 0 (rows into the host pixmap) or 1 (rows to the first GPU)");
             sc->multi->gather = (int)value;
+            return RT355_OK;
+        }
+        if (!strcmp(name, "balance")) {
+            if (value != 0 && value != 1) return fail(RT355_ERR_ARG, "option balance: 0 (interleaved row tiles) or 1 (contiguous slabs cut by the shares' times)");
+            sc->multi->balance = (int)value;
+            sc->multi->slabs = SlabBalance();
             return RT355_OK;
         }
         for (rt355_scene *r : sc->multi->scenes) { const int rc = rt355_scene_set_option(r, name, value); if (rc) return rc; }

@@ -29,6 +29,59 @@ def slab_rows(height: int, world: int) -> List[Tuple[int, int]]:
     return [(edges[i], edges[i + 1]) for i in range(world)]
 
 
+class SlabBalancer:
+    """Row cuts [0, c1, ..., height] of contiguous slabs, moved from frame to frame so that the slabs take the same
+    time.  A slab's time is read as a part every share pays whatever its size (`fixed` of the fastest share's time:
+    launches, fills, the searches' depth) plus the sum of a cost per run of `align` rows (the packets of the search
+    are 16 pixels high); after a frame the costs of a slab's runs are scaled so that they add up to what the slab
+    took -- so the profile keeps what earlier cuts have shown of it, and sharpens where the cuts move -- and the new
+    cuts divide the summed cost evenly.  No slab is left without rows.  Deterministic: every rank computes the same
+    cuts from the same gathered times."""
+
+    def __init__(self, height: int, world: int, align: int = 16, fixed: float = 0.5):
+        if world < 1 or height < world:
+            raise ValueError(f"{world} ranks for {height} rows: a slab would be empty")
+        self.height, self.world, self.fixed = height, world, fixed
+        self.align = align if height >= world * align else 1
+        self.n_runs = (height + self.align - 1) // self.align
+        self.cost = [1.0] * self.n_runs          # per run of rows, in arbitrary units until the first update
+        self.cuts = [b for b, _ in slab_rows(height, world)] + [height]
+        if self.align > 1:                       # (cuts on whole runs, every slab at least one)
+            self.cuts = self._cuts_of()
+
+    def slabs(self) -> List[Tuple[int, int]]:
+        return [(self.cuts[k], self.cuts[k + 1]) for k in range(self.world)]
+
+    def _cuts_of(self) -> List[int]:
+        total, n, cuts = sum(self.cost), self.world, [0]
+        run, done = 0, 0.0                       # runs before `run` add up to `done`
+        for j in range(1, n):
+            want = total * j / n
+            while run < self.n_runs - 1 and done + self.cost[run] <= want:
+                done += self.cost[run]
+                run += 1
+            # the cut goes to the nearer end of the run the target falls in
+            at = run + (1 if want - done > 0.5 * self.cost[run] else 0)
+            lo, hi = cuts[-1] // self.align + 1, self.n_runs - (n - j)
+            cuts.append(max(lo, min(hi, at)) * self.align)
+        cuts.append(self.height)
+        return cuts
+
+    def update(self, times: List[float]) -> List[int]:
+        """Take the times the slabs of the current cuts took (one per rank, any unit); returns the new cuts."""
+        if len(times) != self.world:
+            raise ValueError("one time per slab")
+        floor = self.fixed * min(times)
+        for k, t in enumerate(times):
+            first, last = self.cuts[k] // self.align, (self.cuts[k + 1] + self.align - 1) // self.align
+            have = sum(self.cost[first:last])
+            scale = max(t - floor, 1e-9) / max(have, 1e-30)
+            for r in range(first, last):
+                self.cost[r] *= scale
+        self.cuts = self._cuts_of()
+        return self.cuts
+
+
 def tile_rows_of(height: int, world: int, rank: int, tile_rows: int = TILE_ROWS) -> List[Tuple[int, int]]:
     """The row ranges [begin, end) of rank's share of the interleaved row tiles: what rt355_opts
     (tile_rows, tile_count = world, tile_phase = rank) makes a call render.  May be empty."""
@@ -97,6 +150,10 @@ class SharedPixmap:
                 os.unlink(name[0])
         self.array = np.frombuffer(self._map, dtype=np.uint8, count=n).reshape(height, width, 3)
         self._arrived = np.frombuffer(self._map, dtype=np.int64, count=world, offset=flags_at)
+        if world > 128:
+            raise ValueError("the shared page holds the counters and times of at most 128 ranks")
+        # ... and, in the page's second half, two rows of one time per rank (see barrier_with_times)
+        self._times = np.frombuffer(self._map, dtype=np.float64, count=2 * world, offset=flags_at + 2048).reshape(2, world)
         # The HIP runtime of this image refuses to page-lock a mapping that a file backs (/dev/shm and memfd alike):
         # `registered` is then False, the pixmap stays pageable, and rt355_render passes a rank's rows through the
         # handle's own page-locked staging memory and a host copy, part by part as they arrive.  The registered
@@ -122,6 +179,16 @@ class SharedPixmap:
             if spins % 4096 == 0 and time.perf_counter() - t0 > timeout_s:
                 raise TimeoutError(f"rank {self.rank}: the other ranks did not finish frame {self._epoch} within {timeout_s} s")
 
+    def barrier_with_times(self, mine: float, timeout_s: float = 120.0) -> List[float]:
+        """barrier(), with one number per rank exchanged on the way: what this rank's share of the frame took, for the
+        balancing of the next frame's slabs (SlabBalancer).  A rank writes its number into the row of the current
+        frame's parity before it arrives and reads the whole row after the barrier; the other row is the next
+        frame's, which no rank can be done with before every rank has passed this barrier."""
+        row = self._times[(self._epoch + 1) & 1]
+        row[self.rank] = mine
+        self.barrier(timeout_s)
+        return [float(v) for v in row]
+
     def close(self):
         if self.array is not None:
             if self.registered:
@@ -130,6 +197,7 @@ class SharedPixmap:
                 self.registered = False
             self.array = None
             self._arrived = None
+            self._times = None
             try:
                 self._map.close()
             except BufferError:  # (a view of the array is still alive somewhere: the mapping goes with it)

@@ -1,10 +1,8 @@
 """bench.py's final line: formatted from synthetic results of the size a default run produces, it stays a few
 kilobytes, parses, and carries the contract's keys with `roofline` and `cpu_baseline` on the headline."""
-import io
 import json
 import os
 import sys
-from contextlib import redirect_stdout
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -40,15 +38,14 @@ def _result(name, searched=True, world=1):
     return d
 
 
-def test_line_is_compact_and_complete():
+def test_line_is_compact_and_complete(capfd):
     head = _result("default_4k", searched=False)
     others = {n: _result(n) for n in bench.OTHERS}
     scaling = {n: _result(n, world=8) for n in bench.SCALING}
     line = bench.compact_line(head, others, scaling, 1, 20, 5)
-    buf = io.StringIO()
-    with redirect_stdout(buf):
-        text = bench.emit(line, dict(line, headline=head, other_configs=others))
-    printed = buf.getvalue()
+    capfd.readouterr()
+    text = bench.emit(line, dict(line, headline=head, other_configs=others))  # (written to the descriptor itself)
+    printed = capfd.readouterr().out
     assert printed.endswith(text + "\n") and printed.count("\n") == 1 and printed.startswith("{")
     assert len(text) < 4096 < bench.LINE_LIMIT
     d = json.loads(text)
@@ -69,6 +66,19 @@ def test_line_is_compact_and_complete():
     detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
     assert detail["headline"]["roofline"]["note"] and set(detail["other_configs"]) == set(bench.OTHERS)
     os.remove(os.path.join(ROOT, "bench_detail.json"))
+
+
+def test_nothing_else_reaches_standard_output(tmp_path):
+    """Whatever a library prints on standard output while the bench runs (gloo reports its connections there, in lines
+    that begin with a bracket) goes to standard error: the line is all that the original descriptor receives."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.own_stdout(); "
+            "os.write(1, b'[Gloo] Rank 0 is connected\\n'); print('[library] chatter'); "
+            "bench.say_line('{\"ok\": 1}'); print('more chatter')" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == '{"ok": 1}\n'
+    assert "[Gloo] Rank 0" in p.stderr and "chatter" in p.stderr
 
 
 def test_issue_fraction_from_the_committed_counters(tmp_path, monkeypatch):

@@ -78,6 +78,37 @@ def test_multi_more_devices_than_tiles(api):
     multi.close()
 
 
+@pytest.mark.parametrize("name", ["spheres300", "mirrors_mesh", "default_2lights"])
+def test_multi_balanced_slabs_equal_single_device_frame(api, name):
+    """Option "balance": contiguous slabs whose cuts move from call to call by what the shares took -- the frame stays
+    the single-device frame whatever the cuts are, in both gathers, for a slab of the frame, and for frames of fewer
+    rows than devices (which go in tiles)."""
+    sc, sh, cam, w, h = S.small_case(name)
+    one = api.Renderer(sc)
+    want, wst = one.render(cam, sh, w, h)
+    multi = api.Renderer(sc, devices=[0, 0, 0])
+    multi.set_option("balance", 1)
+    for gather in (0, 1):
+        multi.set_option("gather", gather)
+        for call in range(5):  # (the cuts move after every call)
+            got, st = multi.render(cam, sh, w, h, out=np.full((h, w, 3), 7, dtype=np.uint8))
+            assert np.array_equal(got, want), (name, gather, call)
+            for k in KEYS:
+                assert st[k] == wst[k], (name, gather, call, k)
+    kw = {"row_begin": h // 5, "row_end": h - h // 4}
+    want_slab, _ = one.render(cam, sh, w, h, out=np.full((h, w, 3), 9, dtype=np.uint8), **kw)
+    for call in range(3):
+        got, _ = multi.render(cam, sh, w, h, out=np.full((h, w, 3), 9, dtype=np.uint8), **kw)
+        assert np.array_equal(got, want_slab), call
+    tiny, _ = one.render(S.default_camera(64, 2), sh, 64, 2)
+    got, _ = multi.render(S.default_camera(64, 2), sh, 64, 2)
+    assert np.array_equal(got, tiny)
+    with pytest.raises(api.Rt355Error, match="balance"):
+        multi.set_option("balance", 2)
+    one.close()
+    multi.close()
+
+
 def test_multi_sweep_deals_frames_round_robin(api):
     w, h = 160, 96
     sc = S.mesh_scene(4000, seed=356, tex_size=64)

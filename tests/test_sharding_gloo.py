@@ -40,6 +40,18 @@ def _worker(rank, world, port, out_dir):
     shared.barrier()  # the frame-complete signal: arrival counters in the mapping itself
     for _ in range(50):  # (and again and again: a rank may be a whole frame ahead of a slower one, never two)
         shared.barrier()
+    # the barrier that carries one number per rank (what its share took): every rank reads every rank's, frame after
+    # frame, and balancers fed with them stay the same on all ranks
+    from raytracer_amd.sharding import SlabBalancer
+    bal = SlabBalancer(h, world, align=4)
+    for it in range(20):
+        times = shared.barrier_with_times(100.0 * it + rank + 1.0)
+        assert times == [100.0 * it + r_ + 1.0 for r_ in range(world)], times
+        bal.update(times)
+    cuts = torch.tensor(bal.cuts, dtype=torch.int64)
+    both = [torch.zeros_like(cuts) for _ in range(world)]
+    dist.all_gather(both, cuts)
+    assert all(torch.equal(c, cuts) for c in both)
     dist.barrier()
     if rank == 0:
         np.save(os.path.join(out_dir, "shared.npy"), shared.array.copy())
@@ -104,6 +116,37 @@ def test_slab_rows_cover_frame():
         slab_rows(0, 2)
     with pytest.raises(ValueError):   # an empty slab would read as "the whole frame" at the C ABI
         slab_rows(3, 8)
+
+
+def test_slab_balancer():
+    """Cuts that follow the shares' times: they cover the frame, leave no slab empty, stay on the alignment, and settle
+    where the slabs of a frame with a costly band take the same time."""
+    from raytracer_amd.sharding import SlabBalancer
+    for h, n in ((4320, 8), (2160, 8), (600, 3), (64, 4), (10, 8), (8, 8), (1, 1)):
+        bal = SlabBalancer(h, n)
+        for it in range(6):
+            slabs = bal.slabs()
+            assert slabs[0][0] == 0 and slabs[-1][1] == h and len(slabs) == n
+            assert all(slabs[i][1] == slabs[i + 1][0] for i in range(n - 1)) and all(e > b for b, e in slabs)
+            if h >= 16 * n:
+                assert all(b % 16 == 0 for b, _ in slabs)
+            bal.update([1.0 + ((7 * k + it) % 5) for k in range(n)])
+    with pytest.raises(ValueError):
+        SlabBalancer(3, 8)
+    h, n = 4320, 8
+
+    def cost(r):  # per row: a costly band at the horizon, a cheap sky below
+        return 0.02 + (3.0 if 1700 < r < 2100 else 0.3 if r <= 1700 else 0.01)
+    bal = SlabBalancer(h, n)
+    first = None
+    for it in range(8):
+        times = [0.25 + sum(cost(r) for r in range(b, e)) / 1000 for b, e in bal.slabs()]
+        first = first or max(times) / (sum(times) / n)
+        bal.update(times)
+    times = [0.25 + sum(cost(r) for r in range(b, e)) / 1000 for b, e in bal.slabs()]
+    assert first > 2.5 and max(times) / (sum(times) / n) < 1.1
+    with pytest.raises(ValueError):
+        bal.update([1.0] * (n - 1))
 
 
 def test_tile_shares_cover_frame():

@@ -36,11 +36,11 @@ def test_two_ranks_whole_frames():
     two = _bench("--gpus", "2")
     # the headline keeps its roofline and CPU baseline at N > 1 (rank 0's, for frames it rendered whole)
     assert two["roofline"]["frac"] > 0 and two["cpu_baseline"]["value"] > 0 and two["cpu_baseline"]["parity_sample"] == "ok"
-    # the plain `--gpus N` run measures the scaling workloads: the 8K and 4K frames in tiles between the ranks, the sweep
+    # the plain `--gpus N` run measures the scaling workloads: the 8K and 4K frames in balanced slabs between the ranks, the sweep
     sw = two["scaling_workloads"]
     assert set(sw) == {"mesh1m_8k_tiles", "spheres10k_tiles", "mesh100k_sweep60"}
     for name in ("mesh1m_8k_tiles", "spheres10k_tiles"):
-        assert sw[name]["gathered_frame"] == "ok" and sw[name]["scaling"] == "strong" and sw[name]["shard"] == "tiles"
+        assert sw[name]["gathered_frame"] == "ok" and sw[name]["scaling"] == "strong" and sw[name]["shard"] == "balanced"
     assert all(v["ms"] > 0 and v["value"] > 0 for v in sw.values())
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["workload"] == one["config"]["workload"]
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
