@@ -22,15 +22,16 @@ N > 1: one rank per GPU, launched by torch.distributed.run or, when WORLD_SIZE i
 script itself before it touches the GPU.  Ranks render whole frames independently (--shard frames: weak
 scaling, no data-path collective; a sweep deals its frames round robin, frame f on rank f mod N, a fixed
 total) or one frame between them (--shard slabs: contiguous row slabs; --shard tiles: interleaved 32-row
-tiles; a fixed total), followed by the only exchange of the path: the gather of the final frame over RCCL
-and its readback on rank 0.
+tiles; --shard balanced: slabs whose cuts follow the times the ranks' shares took; a fixed total), the frame
+coming together in one pixmap in host memory that all ranks write their rows into (or, --gather xgmi, on
+rank 0's GPU over RCCL, read back from there).
 
 Prints ONE compact JSON line on rank 0 as the last thing the run writes (a few kilobytes: headline, its roofline
 and CPU baseline, five numbers per other workload, the scaling workloads); the full record of every workload goes to
 bench_detail.json beside this script (and to gpurun_out/ where that directory exists).  Progress lines go to stderr
 before it, prefixed "bench:".
 
-The scaling workloads -- the million-triangle 8K frame and the 10 000-sphere 4K frame in interleaved 32-row tiles, and
+The scaling workloads -- the million-triangle 8K frame and the 10 000-sphere 4K frame in balanced slabs, and
 the 60-camera sweep -- are measured after the headline at every N: at N = 1 the one GPU renders all of each, at N > 1
 the ranks share them ("scaling_workloads" of the line).
 """
@@ -943,7 +944,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=HEADLINE)
     ap.add_argument("--shard", choices=["frames", "slabs", "tiles", "balanced"], default=None,
-                    help="N > 1: whole frames per rank (default), or one frame in row slabs / interleaved 32-row tiles")
+                    help="N > 1: whole frames per rank (default), or one frame in row slabs / interleaved 32-row tiles / slabs cut by the shares' times")
     ap.add_argument("--gather", choices=["host", "xgmi"], default="host",
                     help="--shard slabs|tiles: where the frame comes together -- host: every rank writes its rows into one "
                          "shared page-locked pixmap over its own link; xgmi: rows gathered on GPU 0 (RCCL) and read back there")
