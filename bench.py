@@ -444,7 +444,8 @@ def measure(name, args, ctx, light=False):
         torch.cuda.synchronize()
 
     import gc
-    for _ in range(args.warmup):
+    # (slabs that follow the shares' times need a few frames to find their cuts: at least six untimed steps for them)
+    for _ in range(max(args.warmup, 6) if (split and shared is not None and balancer is not None) else args.warmup):
         step()
     if split and shared is not None and balancer is not None and balance["best_cuts"] is not None:
         # the timed steps run on the best cuts the warm-up found (the same on every rank)
@@ -711,7 +712,8 @@ def measure_inproc(name, args, devices):
         if cams is not None:
             return r.render_sweep(cams, shader, o, arrays)
         return [r.render(cam, shader, w, h, mode=o.mode, shading=shading, out=arrays[0])[1]]
-    for _ in range(args.warmup):
+    balanced = cams is None and shard == "balanced" and n > 1
+    for _ in range(max(args.warmup, 6) if balanced else args.warmup):  # (the cuts need a few frames to settle)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
