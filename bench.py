@@ -512,7 +512,8 @@ def measure(name, args, ctx, light=False):
     if shared is not None:
         gpu_frame = shared.array.copy()
         shared.close()
-    fixed_total = split or (cams is not None and world > 1)
+    # (a frame the ranks share, and a sweep whose frames they deal out, are the same total work at every N -- 1 included)
+    fixed_total = shard in ("slabs", "tiles", "balanced") or cams is not None
     out = {"value": round(value, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4),
            "timed": (("rt355_render of this rank's rows into the one host pixmap all ranks share" + ("" if shared_registered else " (pageable: through each rank's staging memory)") + " + barrier" if args.gather == "host" else
