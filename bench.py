@@ -820,7 +820,8 @@ def compact_cpu(cb):
 def compact_line(head, others, scaling, world, steps, warmup):
     """The ONE line the run ends with: BASELINE's metric on the headline workload with its roofline and CPU baseline,
     five numbers per other workload, the scaling workloads.  Everything else is in bench_detail.json."""
-    out = {"metric": "Mrays/sec (primary+shadow) at 3840x2160", "value": head["value"], "unit": "Mrays/s",
+    out = {"metric": "Mrays/sec (primary+shadow) at %dx%d" % (head["config"]["width"], head["config"]["height"]),  # (the headline: 3840x2160)
+           "value": head["value"], "unit": "Mrays/s",
            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": head["ms_per_step"],
            "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
            "dtype": "f64" if head["config"]["primitives"] < 64 else "f32 search + f64 resolve", "data": "synthetic"}
