@@ -405,6 +405,8 @@ double rt355_strata(uint32_t seed, int32_t x, int32_t y, int32_t which);
  *                     (default 0: the frame's own pipeline renders every camera ray's hit, the trees start from there);
  *                     "refract_single" 1 = one lane per tree in that second step instead of four (measurement aid)
  *   "walk_blocks"     workgroups of the searched gather's walk (default 8192)
+ *   "shade_block"     threads of a workgroup of the camera rays' shading kernel, "direct_block" of the one-kernel
+ *                     renderers of refracted and mirror rays: 64 (default), 128 or 256
  *   "gather"          multi-device scenes only: 0 = every GPU writes its rows into the host pixmap (default), 1 = rows
  *                     gathered on the first device and read back from there
  *   "balance"         multi-device scenes only: 0 = a frame is dealt in interleaved 32-row tiles (default), 1 = in

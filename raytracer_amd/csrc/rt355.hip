@@ -1990,8 +1990,8 @@ __device__ __forceinline__ void store_row_segment(unsigned char *__restrict__ pi
 // lines of the pixmap: 256 neighbouring grid points of one row per workgroup (768 contiguous bytes), 64 per wave.
 #define DIRECT_SEG 64
 __device__ __forceinline__ void direct_xy(const Frame &f, int *x, int *y) {
-    const uint32_t across = (uint32_t)(f.grid_w + 255) / 256u;
-    *x = (int)((blockIdx.x % across) * 256u + threadIdx.x);
+    const uint32_t across = ((uint32_t)f.grid_w + blockDim.x - 1u) / blockDim.x;
+    *x = (int)((blockIdx.x % across) * blockDim.x + threadIdx.x);
     *y = (int)(blockIdx.x / across);
 }
 // ... and what they do with the colour: a sub-sample goes to k_average's array, a pixel to the pixmap
@@ -3564,6 +3564,9 @@ struct Knobs {
     int64_t heavy_workers = HEAVY_WORKERS;     // ... to this many waves
     int64_t heavy_small_rays = HEAVY_SMALL_RAYS; // a call of at most this many rays (a share of a frame) searches a scene of
                                                // HEAVY_SMALL_PRIMS primitives or more in two launches too, handing over after HEAVY_SMALL_AFTER (0: never)
+    int64_t shade_block = 64;                  // threads of a workgroup of the shading kernel: 64, 128 or 256 (its waves share nothing, and one-wave
+                                               // workgroups leave no place on a SIMD idle until the slowest of four waves has finished)
+    int64_t direct_block = 64;                 // threads of a workgroup of the one-kernel renderers of refracted and mirror rays: 64, 128 or 256
     int64_t packet_rays = 0;                   // rays per lane of the packet search: 1 or 4 (0: timed on the first frames)
     int64_t refract_single = 0;                // 1: one lane per listed ray in the second step of such a frame (measurement aid)
     int64_t refract_whole = 0;                 // 1: a searched scene with glass is rendered by the one kernel that walks every ray's tree (the former way)
@@ -3580,7 +3583,7 @@ struct KnobName { const char *name; int64_t Knobs::*field; int64_t lo, hi; };
 static const KnobName kKnobs[] = {
     {"heavy_min_prims", &Knobs::heavy_min_prims, 0, INT32_MAX}, {"heavy_after", &Knobs::heavy_after, 1, INT32_MAX},
     {"heavy_workers", &Knobs::heavy_workers, 1, 1024}, {"heavy_small_rays", &Knobs::heavy_small_rays, 0, INT32_MAX},
-    {"packet_rays", &Knobs::packet_rays, 0, 4},
+    {"packet_rays", &Knobs::packet_rays, 0, 4}, {"shade_block", &Knobs::shade_block, 64, 256}, {"direct_block", &Knobs::direct_block, 64, 256},
     {"gather_general", &Knobs::gather_general, 0, 1}, {"refract_whole", &Knobs::refract_whole, 0, 1}, {"refract_single", &Knobs::refract_single, 0, 1}, {"walk_blocks", &Knobs::walk_blocks, 1, 1 << 20},
     {"readback", &Knobs::readback, 0, 2}, {"render_parts", &Knobs::render_parts, 1, 64}, {"tail_parts", &Knobs::tail_parts, 1, 64},
     {"no_tail_parts", &Knobs::no_tail_parts, 0, 1}, {"tail_bottom_first", &Knobs::tail_bottom_first, 0, 1},
@@ -3590,7 +3593,8 @@ static const KnobName kKnobs[] = {
 static int set_knob(Knobs &k, const char *name, int64_t value) {
     for (const KnobName &kn : kKnobs)
         if (!strcmp(kn.name, name)) {
-            if (value < kn.lo || value > kn.hi || (kn.field == &Knobs::packet_rays && !(value == 0 || value == 1 || value == 4)))
+            if (value < kn.lo || value > kn.hi || (kn.field == &Knobs::packet_rays && !(value == 0 || value == 1 || value == 4)) ||
+                ((kn.field == &Knobs::shade_block || kn.field == &Knobs::direct_block) && !(value == 64 || value == 128 || value == 256)))
                 return fail(RT355_ERR_ARG, std::string("option ") + name + ": value out of range");
             k.*(kn.field) = value;
             return RT355_OK;
@@ -4758,6 +4762,9 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
         const SceneView &v = sc->view;
         const bool few = v.n_planes <= GATHER_FEW && v.n_spheres <= GATHER_FEW && v.n_planes + v.n_spheres == v.n_prims &&
                          !sc->knobs.gather_general;
+        // (the renderers whose pixels differ most in what they cost -- trees of refracted rays, chains of mirror rays -- go in
+        // one-wave workgroups: a place on a SIMD is then free as soon as its wave is done, not when the slowest of four is)
+        const unsigned db = (unsigned)sc->knobs.direct_block, db_blocks = (unsigned)((f.grid_w + (int)db - 1) / (int)db) * (unsigned)f.grid_h;
 #define LAUNCH_GATHER(B, F) hipLaunchKernelGGL((k_render_gather<B, F>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, ga, pix)
         if (opts->shading == RT355_SHADING_BLEED) {
             if (few) LAUNCH_GATHER(true, GATHER_FEW); else LAUNCH_GATHER(true, 0);
@@ -4765,13 +4772,13 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             if (few) LAUNCH_GATHER(false, GATHER_FEW); else LAUNCH_GATHER(false, 0);
         }
 #undef LAUNCH_GATHER
-#define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, pix)
+#define LAUNCH_DIRECT(R, E) hipLaunchKernelGGL((k_render_direct<R, E>), dim3(R ? db_blocks : direct_blocks), dim3(R ? db : 256u), 0, st, sc->view, sh, dc, f, w, pix)
         else if (refract) {
             // scenes of many primitives find their candidates through the scene table (not in mode BRUTE, and not
             // from the entry point that has no workspace)
             const bool walk = sc->has_general && sc->view.n_prims >= SEARCH_MIN_PRIMS && opts->mode != RT355_MODE_BRUTE && !noalloc;
             if (walk) HIP_TRY(hipMemsetAsync(w.spill.count, 0, sizeof(uint32_t), st));
-#define LAUNCH_REFRACT(S, W) hipLaunchKernelGGL((k_render_refract<S, W>), dim3(direct_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix)
+#define LAUNCH_REFRACT(S, W) hipLaunchKernelGGL((k_render_refract<S, W>), dim3(db_blocks), dim3(db), 0, st, sc->view, sh, dc, f, w, sc->general, pix)
             if (soft) { if (walk) LAUNCH_REFRACT(true, true); else LAUNCH_REFRACT(true, false); }
             else { if (walk) LAUNCH_REFRACT(false, true); else LAUNCH_REFRACT(false, false); }
 #undef LAUNCH_REFRACT
@@ -4848,7 +4855,9 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             hipLaunchKernelGGL(k_count_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, f.n_rays, w.tile_stride, one);
             hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tile_count, (int)n_tiles, w.tile_stride, one);
             hipLaunchKernelGGL(k_scatter_active, dim3(n_tiles, 1), dim3(SEARCH_THREADS), 0, st, w.ray32, w.tile_count, w.active_rid, f.n_rays, w.tile_stride, w.list_stride, one);
-            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks), dim3(256), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
+            // (one-wave workgroups: the walks of a wave's rays differ a great deal in length, and a place on a SIMD is free
+            // as soon as its wave is done -- the three searches of the mirror frame 2.00 -> 1.87 ms)
+            hipLaunchKernelGGL(k_search_general, dim3(per_ray_blocks * 4u), dim3(64), 0, st, sc->general, sc->view, w.ray_d, w.active_rid,
                                w.tile_count + n_tiles, f.n_rays, w.cand, w.cand_cnt, w.spill, w.counters, w.lvl_live + L);
             HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches + 1], st));
             sc->bk().launch_choice.push_back({-1, 0});
@@ -4892,12 +4901,14 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
                     blocks = (tail_first_rid(p + 1) - fp.rid_base) / 256u;
                     if (blocks == 0) continue; // (a frame of fewer tile rows than parts)
                 }
+                const unsigned sb = L == 0 ? (unsigned)sc->knobs.shade_block : 256u; // (the levels of mirror rays: 1 % slower in one-wave workgroups)
+                blocks *= 256u / sb;
                 if (soft)
-                    hipLaunchKernelGGL((k_shade_group<true, true>), dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
+                    hipLaunchKernelGGL((k_shade_group<true, true>), dim3(blocks), dim3(sb), 0, st, sc->view, sh, fp, w, cur, next, pix);
                 else if (sc->view.n_envs + sc->view.n_quadrics > 0)
-                    hipLaunchKernelGGL(k_shade_group<true>, dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
+                    hipLaunchKernelGGL(k_shade_group<true>, dim3(blocks), dim3(sb), 0, st, sc->view, sh, fp, w, cur, next, pix);
                 else
-                    hipLaunchKernelGGL(k_shade_group<false>, dim3(blocks), dim3(256), 0, st, sc->view, sh, fp, w, cur, next, pix);
+                    hipLaunchKernelGGL(k_shade_group<false>, dim3(blocks), dim3(sb), 0, st, sc->view, sh, fp, w, cur, next, pix);
                 if (shade_in_parts && (rc1 = tail_finish(p, turn == tail_parts - 1))) return rc1;
             }
             for (int turn = 0; in_parts && !shade_in_parts && turn < tail_parts; turn++)
@@ -4962,10 +4973,11 @@ static int render_enqueue(rt355_scene *sc, const rt355_camera *cam, const rt355_
             HIP_TRY(hipMemsetAsync(w.far_n, 0, sizeof(uint32_t), st));
             HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches], st));
             hipLaunchKernelGGL(k_list_children, dim3(per_ray_blocks), dim3(256), 0, st, sc->view, f, w);
+            const unsigned cb = (unsigned)sc->knobs.direct_block;
             if (sc->work_slots >= REFRACT_GROUP && !sc->knobs.refract_single) // a group of lanes per listed ray (blocks past the list leave at once)
-                hipLaunchKernelGGL((k_render_refract<false, true, true, REFRACT_GROUP>), dim3(per_ray_blocks * REFRACT_GROUP), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
+                hipLaunchKernelGGL((k_render_refract<false, true, true, REFRACT_GROUP>), dim3(per_ray_blocks * REFRACT_GROUP * (256u / cb)), dim3(cb), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
             else
-                hipLaunchKernelGGL((k_render_refract<false, true, true>), dim3(per_ray_blocks), dim3(256), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
+                hipLaunchKernelGGL((k_render_refract<false, true, true>), dim3(per_ray_blocks * (256u / cb)), dim3(cb), 0, st, sc->view, sh, dc, f, w, sc->general, pix);
             HIP_TRY(hipEventRecord(sc->bk().ev_search[2 * launches + 1], st));
             sc->bk().launch_choice.push_back({-1, 0});
             launches++;
