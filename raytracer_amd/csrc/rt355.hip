@@ -3740,7 +3740,7 @@ struct SlabBalance {
             const int first = (cuts[k] - y0) / align, last = (cuts[k + 1] - y0 + align - 1) / align;
             double have = 0;
             for (int r = first; r < last; r++) have += cost[r];
-            const double scale = std::max(ms[k] - 0.5 * fastest, 1e-9) / std::max(have, 1e-30);
+            const double scale = pow(std::max(ms[k] - 0.5 * fastest, 1e-9) / std::max(have, 1e-30), 0.6); // (damped: a full correction swings to and fro)
             for (int r = first; r < last; r++) cost[r] *= scale;
         }
         cut();

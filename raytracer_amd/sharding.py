@@ -35,13 +35,14 @@ class SlabBalancer:
     launches, fills, the searches' depth) plus the sum of a cost per run of `align` rows (the packets of the search
     are 16 pixels high); after a frame the costs of a slab's runs are scaled so that they add up to what the slab
     took -- so the profile keeps what earlier cuts have shown of it, and sharpens where the cuts move -- and the new
-    cuts divide the summed cost evenly.  No slab is left without rows.  Deterministic: every rank computes the same
+    cuts divide the summed cost evenly (the scaling is damped, to the power `gain`: a share's time also moves with what
+    the GPU did just before, and a full correction swings to and fro).  No slab is left without rows.  Deterministic: every rank computes the same
     cuts from the same gathered times."""
 
-    def __init__(self, height: int, world: int, align: int = 16, fixed: float = 0.5):
+    def __init__(self, height: int, world: int, align: int = 16, fixed: float = 0.5, gain: float = 0.6):
         if world < 1 or height < world:
             raise ValueError(f"{world} ranks for {height} rows: a slab would be empty")
-        self.height, self.world, self.fixed = height, world, fixed
+        self.height, self.world, self.fixed, self.gain = height, world, fixed, gain
         self.align = align if height >= world * align else 1
         self.n_runs = (height + self.align - 1) // self.align
         self.cost = [1.0] * self.n_runs          # per run of rows, in arbitrary units until the first update
@@ -75,7 +76,7 @@ class SlabBalancer:
         for k, t in enumerate(times):
             first, last = self.cuts[k] // self.align, (self.cuts[k + 1] + self.align - 1) // self.align
             have = sum(self.cost[first:last])
-            scale = max(t - floor, 1e-9) / max(have, 1e-30)
+            scale = (max(t - floor, 1e-9) / max(have, 1e-30)) ** self.gain
             for r in range(first, last):
                 self.cost[r] *= scale
         self.cuts = self._cuts_of()
