@@ -202,6 +202,32 @@ def test_packet_sizes_give_the_same_frames(api, oracle, rays_per_lane):
         assert st["exact_tests"] == rst["exact_tests"]
 
 
+@pytest.mark.parametrize("threads", [64, 128, 256])
+def test_workgroup_sizes_give_the_same_frames(api, oracle, threads):
+    """The shading kernel and the one-kernel renderers of refracted and mirror rays run in workgroups of one wave by
+    default ("shade_block", "direct_block"); two or four waves must give the same bytes and ray counts, with and
+    without supersampling (whose frame ends in k_average), and for a frame whose width is no multiple of the size."""
+    for name, kw in (("spheres300", {}), ("mesh", {"alias": 2, "seed": 4}), ("glass", {}), ("mirrors", {}), ("mirrors_mesh", {}),
+                     ("glass", {"alias": 2, "seed": 7})):
+        sc, sh, cam, w, h = S.small_case(name)
+        want, wst = oracle.render(sc.pack(), cam, sh, B.opts(w, h, **kw), threads=0)
+        r = api.Renderer(sc)
+        r.set_option("shade_block", threads)
+        r.set_option("direct_block", threads)
+        got, st = r.render(cam, sh, w, h, **kw)
+        _compare(got, want)
+        assert st["shadow_rays"] == wst["shadow_rays"] and st["secondary_rays"] == wst["secondary_rays"], name
+        w2, h2 = 157, 61
+        want2, _ = oracle.render(sc.pack(), S.default_camera(w2, h2), sh, B.opts(w2, h2), threads=0)
+        got2, _ = r.render(S.default_camera(w2, h2), sh, w2, h2)
+        _compare(got2, want2)
+        r.close()
+    r = api.Renderer(S.small_case("glass")[0])
+    with pytest.raises(api.Rt355Error, match="shade_block"):
+        r.set_option("shade_block", 96)
+    r.close()
+
+
 def test_frames_do_not_change_while_the_packet_size_is_tuned(api):
     """Frames 1 and 2 of a handle try the two packet sizes, later ones use the faster: same bytes throughout."""
     sc, sh, cam, w, h = S.small_case("mesh_dir")
