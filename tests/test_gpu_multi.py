@@ -100,6 +100,10 @@ def test_multi_balanced_slabs_equal_single_device_frame(api, name):
     for call in range(3):
         got, _ = multi.render(cam, sh, w, h, out=np.full((h, w, 3), 9, dtype=np.uint8), **kw)
         assert np.array_equal(got, want_slab), call
+    want_ss, _ = one.render(cam, sh, w, h, alias=2, seed=5)
+    for call in range(3):  # (supersampled: the slabs are rows of pixels, each of alias rows of sub-samples)
+        got, _ = multi.render(cam, sh, w, h, alias=2, seed=5)
+        assert np.array_equal(got, want_ss), call
     tiny, _ = one.render(S.default_camera(64, 2), sh, 64, 2)
     got, _ = multi.render(S.default_camera(64, 2), sh, 64, 2)
     assert np.array_equal(got, tiny)
